@@ -1,0 +1,180 @@
+/*
+ * ohw.h — C ABI of libohw.so, the MI355X-native Whisper hot path for OpenHush.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own for this path: it calls
+ * whisper.cpp through the `whisper-rs` crate (reference src/engine/whisper.rs:10-12).  Each entry
+ * point below names the reference call site it replaces; INTEGRATION.md shows the Rust `extern "C"`
+ * block and the `WhisperEngine` impl a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain C, opaque handles, caller-allocated outputs, no exceptions/aborts across the boundary;
+ *   - every function returns OHW_OK (0) or a negative code; ohw_last_error() gives the text of the
+ *     last failure on the calling thread;
+ *   - handles carry no thread affinity (the reference builds the engine on a tokio thread and
+ *     moves it to the `transcription-worker` thread: reference src/queue/worker.rs:22,100-103);
+ *     every call selects its device itself.  Calls on ONE state must be serial (the reference
+ *     serialises with RefCell::borrow_mut, src/engine/whisper.rs:240);
+ *   - the library fails loudly: no CPU fallback exists.  Without a usable gfx950 device
+ *     ohw_ctx_create* returns OHW_E_NO_GPU (reference error taxonomy OH-3004).
+ */
+#ifndef OHW_H
+#define OHW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OHW_ABI_VERSION 1
+
+/* error codes: the negated OH-30xx taxonomy the reference documents
+ * (reference .claude/knowledge/error-codes.md:79-104; WhisperError variants src/engine/whisper.rs:14-27) */
+enum {
+  OHW_OK = 0,
+  OHW_E_MODEL_NOT_FOUND = -3001, /* WhisperError::ModelNotFound   */
+  OHW_E_LOAD_FAILED = -3002,     /* WhisperError::LoadFailed      */
+  OHW_E_TRANSCRIBE = -3003,      /* WhisperError::TranscriptionFailed */
+  OHW_E_NO_GPU = -3004,
+  OHW_E_OOM = -3005,
+  OHW_E_INVALID_ARG = -3006,
+  OHW_E_VALIDATION = -3007       /* WhisperError::ValidationFailed (code in ohw_audio_info.error) */
+};
+
+/* compute dtype of weights/activations fed to MFMA (accumulation, LN, softmax, logits: fp32) */
+enum { OHW_DTYPE_BF16 = 0, OHW_DTYPE_F16 = 1 };
+
+/* log-mel tail convention */
+enum { OHW_MEL_REFLECT = 0 /* feature-extractor convention, pinned by goldens */,
+       OHW_MEL_ZERO_TAIL = 1 /* whisper.cpp convention: zeros after the audio */ };
+
+typedef struct ohw_ctx ohw_ctx;     /* model: weights resident in HBM  (whisper-rs WhisperContext) */
+typedef struct ohw_state ohw_state; /* activations, KV caches, streams  (whisper-rs WhisperState)   */
+
+typedef struct {
+  int32_t n_vocab, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+  int32_t n_text_ctx, n_text_state, n_text_head, n_text_layer, n_mels, ftype;
+} ohw_hparams;
+
+typedef struct {
+  int32_t eot, sot, translate, transcribe, solm, prev, nosp, no_timestamps, timestamp_begin, blank;
+  int32_t n_langs;
+} ohw_special_tokens;
+
+/* ---- audio validation: reference src/engine/validation.rs:46-118 (validate_audio) ------------- */
+enum { OHW_AUDIO_OK = 0, OHW_AUDIO_EMPTY = 1, OHW_AUDIO_BAD_RATE = 2, OHW_AUDIO_TOO_LONG = 3,
+       OHW_AUDIO_TOO_SHORT = 4, OHW_AUDIO_NAN = 5, OHW_AUDIO_INF = 6 };
+typedef struct {
+  int32_t error;          /* OHW_AUDIO_* */
+  float duration_secs;
+  int64_t sample_count;
+  float min_value, max_value, rms;
+  int64_t nan_count, inf_count;
+} ohw_audio_info;
+/* host-side scan, same order of checks and same arithmetic as the reference */
+int ohw_validate_audio(const float* samples, int64_t n, uint32_t sample_rate, ohw_audio_info* info);
+
+/* ---- model: replaces WhisperContext::new_with_params (reference src/engine/whisper.rs:156-160) - */
+/* model_path: a ggml `ggml-*.bin` file (reference src/engine/whisper.rs:71-79).  A missing file   */
+/* returns OHW_E_MODEL_NOT_FOUND before any device work (reference :141-154, test :984-997).       */
+int ohw_ctx_create(const char* model_path, int device, int dtype, ohw_ctx** out);
+/* procedural weights generated on the device (tests / bench; openhush_amd/synth.py is the spec)  */
+int ohw_ctx_create_synthetic(const ohw_hparams* hp, uint32_t seed, int device, int dtype, ohw_ctx** out);
+int ohw_ctx_info(const ohw_ctx* ctx, ohw_hparams* hp, ohw_special_tokens* tok);
+/* bytes of token `id` (text tokens only); returns length, 0 for specials                         */
+int ohw_token_text(const ohw_ctx* ctx, int32_t id, const char** text);
+void ohw_ctx_free(ohw_ctx* ctx); /* WhisperContext drop */
+
+/* ---- state: replaces ctx.create_state() (reference src/engine/whisper.rs:167-169) ------------- */
+/* max_batch = number of independent 30 s windows processed together (the reference: 1)           */
+int ohw_state_create(ohw_ctx* ctx, int max_batch, ohw_state** out);
+void ohw_state_free(ohw_state* st); /* WhisperState drop: frees all device memory */
+/* HIP stream (hipStream_t) every later call on this state enqueues on; NULL = the state's own    */
+int ohw_state_set_stream(ohw_state* st, void* hip_stream);
+int ohw_state_max_batch(const ohw_state* st);
+
+/* ---- the stages of state.full() (reference src/engine/whisper.rs:266-268), split so that the   */
+/*      host keeps windowing and sampling (BASELINE.json north_star) ------------------------------ */
+
+/* log-mel of `batch` windows.  pcm: batch rows of `pcm_stride` floats (host memory, or device     */
+/* memory when pcm_on_device != 0); n_samples[b] <= 480000 valid samples per row (rest = silence). */
+/* mel_out (optional, host or NULL): [batch][n_mels][3000] f32 copy of the normalised log-mel.     */
+int ohw_mel(ohw_state* st, const float* pcm, int64_t pcm_stride, const int32_t* n_samples, int batch,
+            int pcm_on_device, int mel_mode, float* mel_out);
+/* encoder + cross-attention K/V of every decoder layer, for the windows of the last ohw_mel      */
+int ohw_encode(ohw_state* st, int batch);
+/* feed tokens[b][0..n_new) at positions n_past[b].. and return logits of the last fed position    */
+/* per window: logits_out [batch][n_vocab] f32 (host).  tokens: [batch][n_new] row-major.          */
+int ohw_decode(ohw_state* st, const int32_t* tokens, int n_new, const int32_t* n_past, int batch, float* logits_out);
+
+/* sampling parameters: the whisper.cpp defaults the reference inherits because it sets none     */
+/* (reference src/engine/whisper.rs:243-263)                                 */
+typedef struct {
+  int32_t lang_id;        /* 0 = "en": what language "auto" means in the reference */
+  int32_t translate;      /* task token; the reference passes !config.translate (whisper.rs:251-257) */
+  int32_t no_timestamps;  /* 0 */
+  int32_t suppress_blank; /* 1 */
+  int32_t max_initial_ts; /* 50 = 1.0 s / 0.02 s */
+  int32_t n_max;          /* n_text_ctx/2 - 4 = 220 */
+  int32_t force_len;      /* > 0: EOT suppressed, decoding stops after exactly this many tokens    */
+} ohw_sample_params;
+void ohw_default_sample_params(const ohw_ctx* ctx, ohw_sample_params* p);
+
+/* host-side logits filter + arg-max for one window (the "token sampler" the host owns).          */
+/* logits: [n_vocab], modified in place; cur: tokens sampled so far in this window.               */
+int32_t ohw_sample_greedy_host(const ohw_ctx* ctx, const ohw_sample_params* p, float* logits,
+                               const int32_t* cur, int n_cur, float* logprob_out);
+
+/* device-resident greedy loop for the windows of the last ohw_encode: prompt, KV-cached steps,   */
+/* logits filter and arg-max all stay on the GPU; only token ids come back.                        */
+/* tokens_out [batch][max_tokens] i32, n_tokens_out [batch] (host); EOT is not stored.             */
+int ohw_greedy(ohw_state* st, const ohw_sample_params* p, int batch, int32_t* tokens_out, int32_t* n_tokens_out,
+               int max_tokens, float* sum_logprob_out /* [batch] or NULL */);
+
+/* per-stage device time of the last calls on this state, in milliseconds (reference logs the     */
+/* same split per job: src/queue/worker.rs:170-180)                                               */
+typedef struct { float mel_ms, encode_ms, decode_ms, total_ms; int32_t decode_steps; } ohw_timings;
+int ohw_state_timings(ohw_state* st, ohw_timings* t);
+
+/* ---- WhisperEngine mirror (reference src/engine/whisper.rs:110-387): the host driver written   */
+/*      in C++ because no Rust toolchain exists in the build image --------------------------------- */
+typedef struct ohw_engine ohw_engine;
+/* WhisperEngine::new(model_path, language, translate, use_gpu) — reference :129-179              */
+int ohw_engine_new(const char* model_path, const char* language, int translate, int use_gpu, int device,
+                   int dtype, int max_batch, ohw_engine** out);
+/* WhisperEngine::transcribe(&AudioBuffer) — reference :204-310.  Text is copied into text_buf     */
+/* (UTF-8, NUL-terminated, truncated to text_cap).  language_out: >= 8 bytes.                      */
+int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32_t sample_rate,
+                          char* text_buf, size_t text_cap, char* language_out, uint64_t* duration_ms,
+                          ohw_audio_info* info);
+/* tokens of the last transcribe, per 30 s window concatenated (for parity tests)                  */
+int ohw_engine_last_tokens(ohw_engine* e, const int32_t** tokens, int* n);
+/* WhisperEngine::benchmark(safety_margin) — reference :334-387                                    */
+int ohw_engine_benchmark(ohw_engine* e, float safety_margin, float* overhead_secs, float* recommended_chunk_interval,
+                         float* test_audio_secs);
+void ohw_engine_free(ohw_engine* e);
+ohw_state* ohw_engine_state(ohw_engine* e);
+ohw_ctx* ohw_engine_ctx(ohw_engine* e);
+/* lang id -> ISO code ("unknown" outside 0..98): reference lang_id_to_code :627-731               */
+const char* ohw_lang_id_to_code(int32_t id);
+/* ISO code -> lang id, -1 if unknown */
+int32_t ohw_lang_code_to_id(const char* code);
+
+/* ---- diagnostics (tests) ----------------------------------------------------------------------- */
+const char* ohw_last_error(void);
+int ohw_abi_version(void);
+/* copy an internal activation to the host as f32: what = "mel" [B][n_mels][3000], "conv1"        */
+/* [B][3000][d], "stem" / "block0" / "enc" [B][1500][d], "xk<l>" / "xv<l>" [B][1500][d]            */
+int ohw_state_fetch(ohw_state* st, const char* what, int batch, float* out, int64_t out_elems);
+/* copy a weight tensor back as f32 in the model file's layout (checks synthetic == file)          */
+int ohw_ctx_fetch_tensor(const ohw_ctx* ctx, const char* name, float* out, int64_t out_elems);
+/* kernel-level entry points on raw device pointers (tests against a torch fp32 reference)         */
+int ohw_dbg_gemm(int dtype, const void* A, const void* W, const float* bias, void* out, int64_t M, int64_t N,
+                 int64_t K, int epilogue, void* stream);
+int ohw_dbg_attention(int dtype, const void* qkv, void* out, int batch, int T, int n_head, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OHW_H */

@@ -1,0 +1,425 @@
+// decode.hip — kernels of one autoregressive decoder step, gfx950.
+//
+// The step is HBM-bound: every step streams all decoder weights once (1.81 GB bf16 for large-v3,
+// independent of the batch) plus, per window, the cross-attention K/V of every layer (245.8 MB).
+// Layouts are chosen so that every wave-instruction reads 1 KiB of contiguous HBM:
+//   * decoder linears are stored as MFMA fragments [N/16][K/32][64 lanes][8]: a wave streams its
+//     16 output rows as consecutive 1-KiB blocks straight into VGPRs (no LDS round trip: the weights
+//     are used once; cdna_hip_programming.md "GEMV / M <= 16 decode weights"),
+//   * cross K/V are head-major [B][H][1500][64]: one (window, head) = 192 KiB contiguous per tensor.
+#include "kernels.hpp"
+
+namespace ohw {
+
+// ------------------------------------------------------------------------------------------------
+// token + position embedding
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_kernel(const T* __restrict__ emb, const float* __restrict__ pos, const int32_t* __restrict__ tok,
+                             const int32_t* __restrict__ n_past, float* __restrict__ x, int M, int n_new, int d) {
+  const int m = blockIdx.x;
+  const int b = m / n_new, i = m % n_new;
+  const int t = tok[m];
+  const int pp = n_past[b] + i;
+  const int64_t kblocks = d / 32;
+  for (int k = threadIdx.x; k < d; k += blockDim.x) {
+    const int64_t off = ((((int64_t)(t >> 4) * kblocks + (k >> 5)) * 64 + (t & 15) + 16 * ((k & 31) >> 3)) << 3) + (k & 7);
+    x[(int64_t)m * d + k] = (float)emb[off] + pos[(int64_t)pp * d + k];
+  }
+}
+template <typename T>
+void launch_embed(const void* emb, const float* pos, const int32_t* tok, const int32_t* n_past, float* x, int M, int n_new, int d, hipStream_t s) {
+  hipLaunchKernelGGL((embed_kernel<T>), dim3(M), dim3(256), 0, s, (const T*)emb, pos, tok, n_past, x, M, n_new, d);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// skinny GEMM  y[M][N] = x[M][K] * W[N][K]^T  for M <= 32 per pass, W in fragment tiles.
+// grid = (Npad/16, ceil(M/32)); 4 waves split K (interleaved 1-KiB blocks), reduce through LDS in a
+// fixed order (bitwise reproducible, no atomics).
+// ------------------------------------------------------------------------------------------------
+constexpr int DG_THREADS = 256;
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(DG_THREADS) void dec_gemm_kernel(DecGemmParams p) {
+  using Ops = TypeOps<T>;
+  using vec8 = typename Ops::vec8;
+  __shared__ f32x4 part[4][2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = blockIdx.x;
+  const int m0 = blockIdx.y * 32;
+  const int kblocks = p.K / 32;
+  const vec8* __restrict__ wt = (const vec8*)p.w + (int64_t)nt * kblocks * 64 + lane;
+  const T* __restrict__ x = (const T*)p.x;
+  int r0 = m0 + (lane & 15), r1 = m0 + 16 + (lane & 15);
+  if (r0 > p.M - 1) r0 = p.M - 1;
+  if (r1 > p.M - 1) r1 = p.M - 1;
+  const T* x0 = x + (int64_t)r0 * p.K + (lane >> 4) * 8;
+  const T* x1 = x + (int64_t)r1 * p.K + (lane >> 4) * 8;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  int kb = wave;
+  // main loop, 4 k-blocks in flight per wave
+  for (; kb + 12 < kblocks; kb += 16) {
+    vec8 w[4], a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      w[u] = wt[(int64_t)(kb + 4 * u) * 64];
+      a[u] = *(const vec8*)(x0 + (kb + 4 * u) * 32);
+      b[u] = *(const vec8*)(x1 + (kb + 4 * u) * 32);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc0 = Ops::mfma16(w[u], a[u], acc0);
+      acc1 = Ops::mfma16(w[u], b[u], acc1);
+    }
+  }
+  for (; kb < kblocks; kb += 4) {
+    vec8 w = wt[(int64_t)kb * 64];
+    vec8 a = *(const vec8*)(x0 + kb * 32);
+    vec8 b = *(const vec8*)(x1 + kb * 32);
+    acc0 = Ops::mfma16(w, a, acc0);
+    acc1 = Ops::mfma16(w, b, acc1);
+  }
+  part[wave][0][lane] = acc0;
+  part[wave][1][lane] = acc1;
+  __syncthreads();
+  // 2 m-tiles x 64 lanes x 4 regs = 512 outputs; thread -> (mt, lane', reg pair)
+  // D layout: n = 4*(lane'>>4) + reg, m = mt*16 + (lane' & 15)
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int o = tid + rep * DG_THREADS;      // 0..511
+    const int mt = o >> 8, ll = (o >> 2) & 63, reg = o & 3;
+    const float* pp = (const float*)&part[0][0][0];
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += pp[((w * 2 + mt) * 64 + ll) * 4 + reg];
+    const int n = nt * 16 + 4 * (ll >> 4) + reg;
+    const int m = m0 + mt * 16 + (ll & 15);
+    if (m >= p.M || n >= p.N) continue;
+    if (p.bias) v += p.bias[n];
+    if constexpr (EPI == DEPI_QKV) {
+      const int d = p.d_model;
+      if (n < d) {
+        ((T*)p.out)[(int64_t)m * d + n] = (T)v;
+      } else {
+        const int b = m / p.n_new, i = m % p.n_new;
+        const int pos = p.n_past[b] + i;
+        const int nn = n < 2 * d ? n - d : n - 2 * d;
+        const int h = nn >> 6, dh = nn & 63;
+        T* cache = (T*)(n < 2 * d ? p.k_cache : p.v_cache);
+        if (pos < p.n_ctx) cache[((((int64_t)b * p.n_head + h) * p.n_ctx + pos) << 6) + dh] = (T)v;
+      }
+    } else if constexpr (EPI == DEPI_BIAS_T) {
+      ((T*)p.out)[(int64_t)m * p.ld_out + n] = (T)v;
+    } else if constexpr (EPI == DEPI_BIAS_GELU_T) {
+      ((T*)p.out)[(int64_t)m * p.ld_out + n] = (T)gelu_erf(v);
+    } else if constexpr (EPI == DEPI_BIAS_RESID) {
+      ((float*)p.out)[(int64_t)m * p.ld_out + n] += v;
+    } else if constexpr (EPI == DEPI_LOGITS) {
+      if (m % p.n_new == p.n_new - 1) ((float*)p.out)[(int64_t)(m / p.n_new) * p.ld_out + n] = v;
+    }
+  }
+}
+
+template <typename T>
+void launch_dec_gemm(const DecGemmParams& p, int epilogue, hipStream_t s) {
+  if (p.K % 32 != 0) throw Error(OHW_E_INVALID_ARG, "dec_gemm: K must be a multiple of 32");
+  dim3 grid((p.N + 15) / 16, (p.M + 31) / 32);
+  switch (epilogue) {
+    case DEPI_QKV: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_QKV>), grid, dim3(DG_THREADS), 0, s, p); break;
+    case DEPI_BIAS_T: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_BIAS_T>), grid, dim3(DG_THREADS), 0, s, p); break;
+    case DEPI_BIAS_GELU_T: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_BIAS_GELU_T>), grid, dim3(DG_THREADS), 0, s, p); break;
+    case DEPI_BIAS_RESID: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_BIAS_RESID>), grid, dim3(DG_THREADS), 0, s, p); break;
+    case DEPI_LOGITS: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_LOGITS>), grid, dim3(DG_THREADS), 0, s, p); break;
+    default: throw Error(OHW_E_INVALID_ARG, "dec_gemm: unknown epilogue");
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// masked self-attention over the KV cache: one wave per (row m, head)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
+                                                       const int32_t* __restrict__ n_past, T* __restrict__ out, int n_new,
+                                                       int n_head, int n_ctx) {
+  __shared__ float qs[64];
+  __shared__ float ps[448 + 64];
+  const int lane = threadIdx.x;
+  const int h = blockIdx.x, m = blockIdx.y;
+  const int b = m / n_new, i = m % n_new;
+  const int d = n_head * 64;
+  int n_keys = n_past[b] + i + 1;
+  if (n_keys > n_ctx) n_keys = n_ctx;
+  qs[lane] = (float)q[(int64_t)m * d + h * 64 + lane] * 0.125f;
+  __syncthreads();
+  const T* kb = kc + (((int64_t)b * n_head + h) * n_ctx << 6);
+  const T* vb = vc + (((int64_t)b * n_head + h) * n_ctx << 6);
+  float mx = -INFINITY;
+  for (int j = lane; j < n_keys; j += 64) {
+    const vec8_t<T>* kr = (const vec8_t<T>*)(kb + ((int64_t)j << 6));
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const vec8_t<T> kv = kr[c];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += qs[c * 8 + e] * (float)kv[e];
+    }
+    ps[j] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < n_keys; j += 64) {
+    const float e = __expf(ps[j] - mx);
+    ps[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  float o = 0.f;
+  for (int j = 0; j < n_keys; ++j) o += ps[j] * (float)vb[((int64_t)j << 6) + lane];
+  out[(int64_t)m * d + h * 64 + lane] = (T)(o / sum);
+}
+template <typename T>
+void launch_self_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* n_past, void* out, int M, int n_new,
+                      int n_head, int n_ctx, hipStream_t s) {
+  if (n_ctx > 448 + 64) throw Error(OHW_E_INVALID_ARG, "self_attn: n_text_ctx > 512 unsupported");
+  hipLaunchKernelGGL((self_attn_kernel<T>), dim3(n_head, M), dim3(64), 0, s, (const T*)q, (const T*)k_cache, (const T*)v_cache, n_past,
+                     (T*)out, n_new, n_head, n_ctx);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross-attention of one query row against 1500 encoder positions: one workgroup per (row, head).
+// 8 lanes share a key (16 B of the 128-B K/V row each), so every wave-instruction covers 8 keys =
+// 1 KiB contiguous; the 4 waves interleave 8-key groups.  Each 8-lane group keeps its own online
+// softmax state (no cross-lane traffic in the loop beyond the 8-lane dot reduction); the 32 partial
+// states are merged once at the end.
+// ------------------------------------------------------------------------------------------------
+constexpr int XA_THREADS = 256;
+constexpr int XA_UNROLL = 4;
+
+template <typename T>
+__global__ __launch_bounds__(XA_THREADS) void cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ xk, const T* __restrict__ xv,
+                                                                T* __restrict__ out, int n_new, int n_head, int t_len) {
+  __shared__ float red_m[4], red_l[4];
+  __shared__ float red_o[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, m = blockIdx.y;
+  const int b = m / n_new;
+  const int d = n_head * 64;
+  const int part = lane & 7, slot = lane >> 3;
+  const float sc = 0.125f * 1.44269504088896340736f;
+  float qv[8];
+  {
+    const vec8_t<T> qq = *(const vec8_t<T>*)(q + (int64_t)m * d + h * 64 + part * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = (float)qq[e] * sc;
+  }
+  const T* kb = xk + (((int64_t)b * n_head + h) * t_len << 6) + part * 8;
+  const T* vb = xv + (((int64_t)b * n_head + h) * t_len << 6) + part * 8;
+  float mrun = -INFINITY, lrun = 0.f;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const int n_groups = (t_len + 7) / 8;
+  for (int g0 = wave; g0 < n_groups; g0 += 4 * XA_UNROLL) {
+    vec8_t<T> kf[XA_UNROLL], vf[XA_UNROLL];
+    int keys[XA_UNROLL];
+#pragma unroll
+    for (int u = 0; u < XA_UNROLL; ++u) {
+      const int g = g0 + 4 * u;
+      int key = g * 8 + slot;
+      keys[u] = (g < n_groups && key < t_len) ? key : -1;
+      if (key > t_len - 1) key = t_len - 1;
+      kf[u] = *(const vec8_t<T>*)(kb + ((int64_t)key << 6));
+      vf[u] = *(const vec8_t<T>*)(vb + ((int64_t)key << 6));
+    }
+#pragma unroll
+    for (int u = 0; u < XA_UNROLL; ++u) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += qv[e] * (float)kf[u][e];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if (keys[u] < 0) s = -INFINITY;
+      const float mn = fmaxf(mrun, s);
+      // mn == -inf only while every key so far was masked: keep the state untouched then
+      const float alpha = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(mrun - mn);
+      const float pe = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(s - mn);
+      mrun = mn;
+      lrun = lrun * alpha + pe;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = acc[e] * alpha + pe * (float)vf[u][e];
+    }
+  }
+  // merge the 8 slots of this wave (lanes with equal `part`): xor 8, 16, 32
+#pragma unroll
+  for (int o = 8; o <= 32; o <<= 1) {
+    const float m2 = __shfl_xor(mrun, o, 64), l2 = __shfl_xor(lrun, o, 64);
+    const float mn = fmaxf(mrun, m2);
+    const float a1 = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(mrun - mn);
+    const float a2 = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m2 - mn);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float o2 = __shfl_xor(acc[e], o, 64);
+      acc[e] = acc[e] * a1 + o2 * a2;
+    }
+    lrun = lrun * a1 + l2 * a2;
+    mrun = mn;
+  }
+  if (slot == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red_o[wave][part * 8 + e] = acc[e];
+    if (part == 0) { red_m[wave] = mrun; red_l[wave] = lrun; }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float mn = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+    float l = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float a = red_m[w] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(red_m[w] - mn);
+      l += red_l[w] * a;
+      o += red_o[w][tid] * a;
+    }
+    out[(int64_t)m * d + h * 64 + tid] = (T)(o / l);
+  }
+}
+template <typename T>
+void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out, int M, int n_new, int n_head, int t_len, hipStream_t s) {
+  hipLaunchKernelGGL((cross_attn_kernel<T>), dim3(n_head, M), dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_new,
+                     n_head, t_len);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// logits filter + greedy arg-max on the device: restates oracle ref_process_logits / ref_greedy
+// (whisper.cpp defaults).  One workgroup per window.
+// ------------------------------------------------------------------------------------------------
+constexpr int SP_THREADS = 1024;
+
+struct SampState {
+  int is_initial, last_ts, penult_ts, last_seen, suppress_eot;
+};
+
+__device__ __forceinline__ bool sp_allowed(const SamplerParams& p, const SampState& st, int i) {
+  if (i == p.no_ts || i == p.sot || i == p.nosp || i == p.translate || i == p.transcribe || i == p.prev || i == p.solm) return false;
+  if (i > p.sot && i <= p.sot + p.n_langs) return false;
+  if (st.is_initial && p.suppress_blank && (i == p.eot || i == p.blank)) return false;
+  if (st.suppress_eot && i == p.eot) return false;
+  if (p.no_timestamps) return i < p.ts_begin;
+  if (st.last_ts) {
+    if (st.penult_ts) { if (i >= p.ts_begin) return false; }
+    else { if (i < p.eot) return false; }
+  }
+  if (st.is_initial && p.max_initial_ts > 0 && i > p.ts_begin + p.max_initial_ts) return false;
+  if (st.last_seen >= 0 && i >= p.ts_begin && i < st.last_seen) return false;
+  return true;
+}
+
+__device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int i = 1; i < SP_THREADS / 64; ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+  return r;
+}
+
+__global__ __launch_bounds__(SP_THREADS) void sampler_kernel(SamplerParams p) {
+  __shared__ float sh[SP_THREADS / 64];
+  __shared__ float shv[SP_THREADS / 64];
+  __shared__ int shi[SP_THREADS / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (p.done[b]) return;
+  const int np_now = p.n_past[b] + p.advance;
+  const float* lg = p.logits + (int64_t)b * p.ld;
+  int32_t* toks = p.tokens + (int64_t)b * p.max_tokens;
+  const int n_cur = p.n_cur[b];
+  SampState st;
+  st.is_initial = n_cur == 0;
+  st.last_ts = n_cur > 0 && toks[n_cur - 1] >= p.ts_begin;
+  st.penult_ts = n_cur < 2 || toks[n_cur - 2] >= p.ts_begin;
+  st.last_seen = -1;
+  for (int i = n_cur - 1; i >= 0; --i) if (toks[i] >= p.ts_begin) { st.last_seen = toks[i]; break; }
+  st.suppress_eot = p.force_len > 0 && n_cur < p.force_len;
+  const int V = p.n_vocab;
+  // pass 1: max over allowed logits
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += SP_THREADS) if (sp_allowed(p, st, i)) mx = fmaxf(mx, lg[i]);
+  mx = block_reduce(mx, sh, true);
+  // pass 2: sum exp (all), sum exp (timestamps), max text logit
+  float se = 0.f, sts = 0.f, tmax = -INFINITY;
+  for (int i = tid; i < V; i += SP_THREADS) {
+    if (!sp_allowed(p, st, i)) continue;
+    const float v = lg[i];
+    const float e = expf(v - mx);
+    se += e;
+    if (i >= p.ts_begin) sts += e; else tmax = fmaxf(tmax, v);
+  }
+  se = block_reduce(se, sh, false);
+  sts = block_reduce(sts, sh, false);
+  tmax = block_reduce(tmax, sh, true);
+  const float lse = mx + logf(se);
+  bool force_ts = false;
+  if (!p.no_timestamps && sts > 0.f) {
+    const float ts_lp = mx + logf(sts) - lse;
+    const float text_lp = tmax - lse;
+    force_ts = ts_lp > text_lp;
+  }
+  // pass 3: arg-max (lowest index on ties)
+  float bv = -INFINITY; int bi = 0x7fffffff;
+  for (int i = tid; i < V; i += SP_THREADS) {
+    if (!sp_allowed(p, st, i)) continue;
+    if (force_ts && i < p.ts_begin) continue;
+    const float v = lg[i];
+    if (v > bv) { bv = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v2 = __shfl_xor(bv, o, 64);
+    const int i2 = __shfl_xor(bi, o, 64);
+    if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) { shv[tid >> 6] = bv; shi[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < SP_THREADS / 64; ++w)
+      if (shv[w] > bv || (shv[w] == bv && shi[w] < bi)) { bv = shv[w]; bi = shi[w]; }
+    const int n_max = p.force_len > 0 ? p.force_len : p.n_max;
+    bool finished = false;
+    if (bi == p.eot) {
+      finished = true;
+    } else {
+      toks[n_cur] = bi;
+      p.n_cur[b] = n_cur + 1;
+      p.sum_logprob[b] += bv - lse;
+      p.next_tok[b] = bi;
+      if (p.advance) p.n_past[b] = np_now;
+      const int np = np_now;
+      if (n_cur + 1 >= n_max || n_cur + 1 >= p.max_tokens || np + 1 >= p.n_text_ctx) finished = true;
+    }
+    if (finished) { p.done[b] = 1; atomicAdd(p.n_done, 1); }
+  }
+}
+void launch_sampler(const SamplerParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(sampler_kernel, dim3(p.batch), dim3(SP_THREADS), 0, s, p);
+  HIP_CHECK(hipGetLastError());
+}
+
+#define INST(T) \
+  template void launch_dec_gemm<T>(const DecGemmParams&, int, hipStream_t); \
+  template void launch_embed<T>(const void*, const float*, const int32_t*, const int32_t*, float*, int, int, int, hipStream_t); \
+  template void launch_self_attn<T>(const void*, const void*, const void*, const int32_t*, void*, int, int, int, int, hipStream_t); \
+  template void launch_cross_attn<T>(const void*, const void*, const void*, void*, int, int, int, int, hipStream_t);
+INST(bf16_t)
+INST(f16_t)
+#undef INST
+
+}  // namespace ohw

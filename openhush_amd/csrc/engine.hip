@@ -1,0 +1,615 @@
+// engine.hip — ohw_state: activation buffers, KV caches and the stage drivers behind the C ABI
+// (mel -> encoder -> cross K/V -> decoder steps -> device-side greedy loop).
+//
+// Replaces ctx.create_state() and the arithmetic inside state.full()
+// (reference src/engine/whisper.rs:167-169, 266-268).
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <type_traits>
+#include <vector>
+#include <algorithm>
+
+#include "attention.hpp"
+#include "gemm.hpp"
+#include "kernels.hpp"
+#include "model.hpp"
+
+namespace ohw {
+ohw_ctx* ctx_from_file(const char* path, int device, int dtype);
+ohw_ctx* ctx_synthetic(const ohw_hparams* hp, uint32_t seed, int device, int dtype);
+
+thread_local std::string g_last_error;
+
+template <typename F>
+static int guard(F&& f) {
+  try {
+    f();
+    return OHW_OK;
+  } catch (const Error& e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    g_last_error = "host allocation failed";
+    return OHW_E_OOM;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return OHW_E_TRANSCRIBE;
+  } catch (...) {
+    g_last_error = "unknown error";
+    return OHW_E_TRANSCRIBE;
+  }
+}
+}  // namespace ohw
+
+using namespace ohw;
+
+struct ohw_state {
+  ohw_ctx* ctx = nullptr;
+  int max_batch = 0;
+  int enc_batch = 0;  // windows of the last mel / encode
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // front end
+  DevBuf pcm, n_samples, logmel, max_bits, mel_t;
+  // encoder activations
+  DevBuf c1, h, y, qkv, att, ffn, enc;
+  // taps kept for diagnostics (small models / tests only)
+  DevBuf tap_stem, tap_block0;
+  bool taps = false;
+  // decoder
+  DevBuf xkv;      // T [2L][B][H][1500][64]
+  DevBuf self_kv;  // T [L][2][B][H][n_text_ctx][64]
+  DevBuf dx, dy, dq, da, df, logits;
+  DevBuf step_tok, n_past, tokens, n_cur, next_tok, done, n_done, sum_lp;
+  int m_max = 0;
+  int64_t logits_ld = 0;
+  // timing
+  hipEvent_t ev[6]{};
+  ohw_timings last{};
+  int max_tokens = 0;
+};
+
+namespace {
+
+struct Dispatch {
+  template <typename F> static void run(int dtype, F&& f) {
+    if (dtype == OHW_DTYPE_BF16) f((bf16_t*)nullptr);
+    else f((f16_t*)nullptr);
+  }
+};
+
+void state_alloc(ohw_state* st) {
+  const ohw_ctx* c = st->ctx;
+  const ohw_hparams& hp = c->hp;
+  const int64_t B = st->max_batch, d = hp.n_audio_state, dt = hp.n_text_state, T = hp.n_audio_ctx;
+  const int64_t L = hp.n_text_layer, H = hp.n_text_head;
+  st->pcm.alloc((size_t)B * CHUNK_SAMPLES * 4);
+  st->n_samples.alloc((size_t)B * 4);
+  st->logmel.alloc((size_t)B * hp.n_mels * CHUNK_FRAMES * 4);
+  st->max_bits.alloc((size_t)B * 4);
+  st->mel_t.alloc((size_t)B * MEL_ROWS * MEL_CPAD * 2, true);
+  st->c1.alloc((size_t)B * MEL_ROWS * d * 2 + 4 * d * 2, true);  // + slack: the last conv2 row reads 1 row past
+  st->h.alloc((size_t)B * T * d * 4);
+  st->y.alloc((size_t)B * T * d * 2);
+  st->qkv.alloc((size_t)B * T * 3 * d * 2);
+  st->att.alloc((size_t)B * T * d * 2);
+  st->ffn.alloc((size_t)B * T * 4 * d * 2);
+  st->enc.alloc((size_t)B * T * d * 2);
+  st->taps = d <= 512;
+  if (st->taps) {
+    st->tap_stem.alloc((size_t)B * T * d * 4);
+    st->tap_block0.alloc((size_t)B * T * d * 4);
+  }
+  st->xkv.alloc((size_t)2 * L * B * H * T * 64 * 2);
+  st->self_kv.alloc((size_t)L * 2 * B * H * hp.n_text_ctx * 64 * 2, true);
+  st->m_max = (int)B * 8;
+  st->dx.alloc((size_t)st->m_max * dt * 4);
+  st->dy.alloc((size_t)st->m_max * dt * 2);
+  st->dq.alloc((size_t)st->m_max * dt * 2);
+  st->da.alloc((size_t)st->m_max * dt * 2);
+  st->df.alloc((size_t)st->m_max * 4 * dt * 2);
+  st->logits_ld = c->v_pad;
+  st->logits.alloc((size_t)B * st->logits_ld * 4);
+  st->max_tokens = hp.n_text_ctx;
+  st->step_tok.alloc((size_t)st->m_max * 4);
+  st->n_past.alloc((size_t)B * 4, true);
+  st->tokens.alloc((size_t)B * st->max_tokens * 4, true);
+  st->n_cur.alloc((size_t)B * 4, true);
+  st->next_tok.alloc((size_t)B * 4, true);
+  st->done.alloc((size_t)B * 4, true);
+  st->n_done.alloc(16, true);
+  st->sum_lp.alloc((size_t)B * 4, true);
+  for (auto& e : st->ev) HIP_CHECK(hipEventCreate(&e));
+}
+
+template <typename T>
+void run_mel(ohw_state* st, const float* pcm_dev, int64_t stride, int batch, int mode) {
+  const ohw_ctx* c = st->ctx;
+  MelParams p{};
+  p.pcm = pcm_dev; p.pcm_stride = stride; p.n_samples = st->n_samples.as<int32_t>();
+  p.filters = c->mel_filters.as<float>(); p.twiddle = c->twiddle.as<float>(); p.window = c->window.as<float>();
+  p.logmel = st->logmel.as<float>(); p.max_bits = st->max_bits.as<int32_t>(); p.mel_t = st->mel_t.p;
+  p.n_mels = c->hp.n_mels; p.batch = batch; p.mode = mode;
+  launch_mel<T>(p, st->stream);
+}
+
+template <typename T>
+void run_encode(ohw_state* st, int B) {
+  const ohw_ctx* c = st->ctx;
+  const ohw_hparams& hp = c->hp;
+  hipStream_t s = st->stream;
+  const int64_t d = hp.n_audio_state, Tn = hp.n_audio_ctx, M = (int64_t)B * Tn;
+  GemmParams g{};
+  // conv1 (k=3, pad 1) as a GEMM over overlapping rows of the time-major mel image
+  g = GemmParams{};
+  g.A = st->mel_t.p; g.W = c->conv1_w.p; g.bias = c->conv1_b.as<float>();
+  g.out = (T*)st->c1.p + d;  // output row t -> image row 1 + t
+  g.M = (int64_t)B * CHUNK_FRAMES; g.N = d; g.K = 3 * MEL_CPAD;
+  g.lda = MEL_CPAD; g.a_batch_stride = (int64_t)MEL_ROWS * MEL_CPAD; g.rows_per_batch = CHUNK_FRAMES;
+  g.ldc = d; g.c_batch_stride = (int64_t)MEL_ROWS * d;
+  launch_gemm<T>(g, EPI_BIAS_GELU_T, s);
+  // conv2 (k=3, stride 2, pad 1): row t reads image rows 2t .. 2t+2 of conv1's padded output
+  g = GemmParams{};
+  g.A = st->c1.p; g.W = c->conv2_w.p; g.bias = c->conv2_b.as<float>(); g.pos = c->enc_pos.as<float>();
+  g.out = st->h.p;
+  g.M = M; g.N = d; g.K = 3 * d;
+  g.lda = 2 * d; g.a_batch_stride = (int64_t)MEL_ROWS * d; g.rows_per_batch = Tn;
+  g.ldc = d; g.c_batch_stride = Tn * d;
+  launch_gemm<T>(g, EPI_GELU_POS_F32, s);
+  if (st->taps) HIP_CHECK(hipMemcpyAsync(st->tap_stem.p, st->h.p, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
+
+  auto dense = [&](const void* A, int64_t K, const DevBuf& W, const DevBuf& bias, void* out, int64_t N, int epi) {
+    GemmParams q{};
+    q.A = A; q.W = W.p; q.bias = bias.as<float>(); q.out = out;
+    q.M = M; q.N = N; q.K = K; q.lda = K; q.a_batch_stride = 0; q.rows_per_batch = M; q.ldc = N; q.c_batch_stride = 0;
+    launch_gemm<T>(q, epi, s);
+  };
+  for (int l = 0; l < hp.n_audio_layer; ++l) {
+    const EncLayerW& w = c->enc[l];
+    launch_layernorm<T>(st->h.as<float>(), w.ln1.g.as<float>(), w.ln1.b.as<float>(), st->y.p, M, (int)d, s);
+    dense(st->y.p, d, w.wqkv, w.bqkv, st->qkv.p, 3 * d, EPI_BIAS_T);
+    launch_encoder_attention<T>(st->qkv.p, st->att.p, B, (int)Tn, hp.n_audio_head, s);
+    dense(st->att.p, d, w.wo, w.bo, st->h.p, d, EPI_BIAS_RESID_F32);
+    launch_layernorm<T>(st->h.as<float>(), w.ln2.g.as<float>(), w.ln2.b.as<float>(), st->y.p, M, (int)d, s);
+    dense(st->y.p, d, w.w1, w.b1, st->ffn.p, 4 * d, EPI_BIAS_GELU_T);
+    dense(st->ffn.p, 4 * d, w.w2, w.b2, st->h.p, d, EPI_BIAS_RESID_F32);
+    if (l == 0 && st->taps) HIP_CHECK(hipMemcpyAsync(st->tap_block0.p, st->h.p, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
+  }
+  launch_layernorm<T>(st->h.as<float>(), c->ln_post.g.as<float>(), c->ln_post.b.as<float>(), st->enc.p, M, (int)d, s);
+  // cross-attention K/V of every decoder layer in one GEMM: N = 2 * L * d, head-major output
+  g = GemmParams{};
+  g.A = st->enc.p; g.W = c->xkv_w.p; g.bias = c->xkv_b.as<float>(); g.out = st->xkv.p;
+  g.M = M; g.N = (int64_t)2 * hp.n_text_layer * hp.n_text_state; g.K = d;
+  g.lda = d; g.a_batch_stride = Tn * d; g.rows_per_batch = Tn; g.ldc = 0; g.c_batch_stride = 0;
+  g.d_model = hp.n_text_state; g.n_head = hp.n_text_head; g.t_len = (int)Tn; g.batch = B;
+  launch_gemm<T>(g, EPI_CROSSKV_T, s);
+}
+
+// one decoder pass over M = B * n_new rows; tokens in st->step_tok, positions from st->n_past
+template <typename T>
+void run_decoder_step(ohw_state* st, int B, int n_new) {
+  const ohw_ctx* c = st->ctx;
+  const ohw_hparams& hp = c->hp;
+  hipStream_t s = st->stream;
+  const int d = hp.n_text_state, H = hp.n_text_head, C = hp.n_text_ctx, Tn = hp.n_audio_ctx, L = hp.n_text_layer;
+  const int M = B * n_new;
+  if (M > st->m_max) throw Error(OHW_E_INVALID_ARG, "decode: batch * n_new exceeds the state's capacity (8 tokens per window per call)");
+  const int32_t* n_past = st->n_past.as<int32_t>();
+  launch_embed<T>(c->emb.p, c->dec_pos.as<float>(), st->step_tok.as<int32_t>(), n_past, st->dx.as<float>(), M, n_new, d, s);
+  const int64_t kv_layer = (int64_t)st->max_batch * H * C * 64;      // elements per K (or V) cache of one layer
+  const int64_t xkv_slab = (int64_t)B * H * Tn * 64;                 // cross K/V slab (batch of the last encode)
+  auto gemm = [&](const void* x, const DevBuf& w, const DevBuf& bias, void* out, int N, int K, int epi, int64_t ld) {
+    DecGemmParams p{};
+    p.x = x; p.w = w.p; p.bias = bias.p ? bias.as<float>() : nullptr; p.out = out;
+    p.M = M; p.N = N; p.K = K; p.n_new = n_new; p.ld_out = ld; p.n_past = n_past;
+    p.d_model = d; p.n_head = H; p.n_ctx = C;
+    launch_dec_gemm<T>(p, epi, s);
+  };
+  for (int l = 0; l < L; ++l) {
+    const DecLayerW& w = c->dec[l];
+    T* kc = (T*)st->self_kv.p + (int64_t)(2 * l) * kv_layer;
+    T* vc = kc + kv_layer;
+    launch_layernorm<T>(st->dx.as<float>(), w.ln1.g.as<float>(), w.ln1.b.as<float>(), st->dy.p, M, d, s);
+    {
+      DecGemmParams p{};
+      p.x = st->dy.p; p.w = w.wqkv.p; p.bias = w.bqkv.as<float>(); p.out = st->dq.p;
+      p.M = M; p.N = 3 * d; p.K = d; p.n_new = n_new; p.ld_out = d;
+      p.k_cache = kc; p.v_cache = vc; p.n_past = n_past; p.d_model = d; p.n_head = H; p.n_ctx = C;
+      launch_dec_gemm<T>(p, DEPI_QKV, s);
+    }
+    launch_self_attn<T>(st->dq.p, kc, vc, n_past, st->da.p, M, n_new, H, C, s);
+    gemm(st->da.p, w.wo, w.bo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
+    launch_layernorm<T>(st->dx.as<float>(), w.lnx.g.as<float>(), w.lnx.b.as<float>(), st->dy.p, M, d, s);
+    gemm(st->dy.p, w.wxq, w.bxq, st->dq.p, d, d, DEPI_BIAS_T, d);
+    launch_cross_attn<T>(st->dq.p, (const T*)st->xkv.p + (int64_t)(2 * l) * xkv_slab, (const T*)st->xkv.p + (int64_t)(2 * l + 1) * xkv_slab,
+                         st->da.p, M, n_new, H, Tn, s);
+    gemm(st->da.p, w.wxo, w.bxo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
+    launch_layernorm<T>(st->dx.as<float>(), w.ln2.g.as<float>(), w.ln2.b.as<float>(), st->dy.p, M, d, s);
+    gemm(st->dy.p, w.w1, w.b1, st->df.p, 4 * d, d, DEPI_BIAS_GELU_T, 4 * d);
+    gemm(st->df.p, w.w2, w.b2, st->dx.p, d, 4 * d, DEPI_BIAS_RESID, d);
+  }
+  launch_layernorm<T>(st->dx.as<float>(), c->dec_ln.g.as<float>(), c->dec_ln.b.as<float>(), st->dy.p, M, d, s);
+  DevBuf none;
+  gemm(st->dy.p, c->emb, none, st->logits.p, hp.n_vocab, d, DEPI_LOGITS, st->logits_ld);
+}
+
+void fill_sampler(const ohw_state* st, const ohw_sample_params* sp, int B, SamplerParams* p) {
+  const ohw_ctx* c = st->ctx;
+  *p = SamplerParams{};
+  p->logits = st->logits.as<float>(); p->ld = st->logits_ld;
+  p->tokens = st->tokens.as<int32_t>(); p->n_cur = st->n_cur.as<int32_t>(); p->n_past = st->n_past.as<int32_t>();
+  p->next_tok = st->next_tok.as<int32_t>(); p->done = st->done.as<int32_t>(); p->n_done = st->n_done.as<int32_t>();
+  p->sum_logprob = st->sum_lp.as<float>();
+  p->batch = B; p->max_tokens = st->max_tokens; p->n_vocab = c->hp.n_vocab;
+  p->eot = c->tok.eot; p->sot = c->tok.sot; p->translate = c->tok.translate; p->transcribe = c->tok.transcribe;
+  p->solm = c->tok.solm; p->prev = c->tok.prev; p->nosp = c->tok.nosp; p->no_ts = c->tok.no_timestamps;
+  p->ts_begin = c->tok.timestamp_begin; p->blank = c->tok.blank; p->n_langs = c->tok.n_langs;
+  p->suppress_blank = sp->suppress_blank; p->no_timestamps = sp->no_timestamps; p->max_initial_ts = sp->max_initial_ts;
+  p->n_max = sp->n_max; p->force_len = sp->force_len; p->n_text_ctx = c->hp.n_text_ctx;
+}
+
+int build_prompt(const ohw_ctx* c, const ohw_sample_params* sp, int32_t* out) {
+  int n = 0;
+  out[n++] = c->tok.sot;
+  if (c->hp.n_vocab >= 51865) {
+    out[n++] = c->tok.sot + 1 + sp->lang_id;
+    out[n++] = sp->translate ? c->tok.translate : c->tok.transcribe;
+  }
+  if (sp->no_timestamps) out[n++] = c->tok.no_timestamps;
+  return n;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* ohw_last_error(void) { return g_last_error.c_str(); }
+int ohw_abi_version(void) { return OHW_ABI_VERSION; }
+
+int ohw_ctx_create(const char* model_path, int device, int dtype, ohw_ctx** out) {
+  return guard([&] {
+    if (!out) throw Error(OHW_E_INVALID_ARG, "out is null");
+    *out = nullptr;
+    *out = ctx_from_file(model_path, device, dtype);
+  });
+}
+
+int ohw_ctx_create_synthetic(const ohw_hparams* hp, uint32_t seed, int device, int dtype, ohw_ctx** out) {
+  return guard([&] {
+    if (!out) throw Error(OHW_E_INVALID_ARG, "out is null");
+    *out = nullptr;
+    *out = ctx_synthetic(hp, seed, device, dtype);
+  });
+}
+
+int ohw_ctx_info(const ohw_ctx* ctx, ohw_hparams* hp, ohw_special_tokens* tok) {
+  return guard([&] {
+    if (!ctx) throw Error(OHW_E_INVALID_ARG, "ctx is null");
+    if (hp) *hp = ctx->hp;
+    if (tok) *tok = ctx->tok;
+  });
+}
+
+int ohw_token_text(const ohw_ctx* ctx, int32_t id, const char** text) {
+  if (!ctx || id < 0 || (size_t)id >= ctx->vocab.size()) { if (text) *text = ""; return 0; }
+  if (text) *text = ctx->vocab[(size_t)id].c_str();
+  return (int)ctx->vocab[(size_t)id].size();
+}
+
+void ohw_ctx_free(ohw_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  delete ctx;
+}
+
+int ohw_state_create(ohw_ctx* ctx, int max_batch, ohw_state** out) {
+  return guard([&] {
+    if (!ctx || !out) throw Error(OHW_E_INVALID_ARG, "ctx/out is null");
+    if (max_batch < 1 || max_batch > 256) throw Error(OHW_E_INVALID_ARG, "max_batch must be in 1..256");
+    *out = nullptr;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    std::unique_ptr<ohw_state> st(new ohw_state());
+    st->ctx = ctx;
+    st->max_batch = max_batch;
+    HIP_CHECK(hipStreamCreateWithFlags(&st->own_stream, hipStreamNonBlocking));
+    st->stream = st->own_stream;
+    state_alloc(st.get());
+    HIP_CHECK(hipDeviceSynchronize());
+    *out = st.release();
+  });
+}
+
+void ohw_state_free(ohw_state* st) {
+  if (!st) return;
+  (void)hipSetDevice(st->ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto& e : st->ev) if (e) (void)hipEventDestroy(e);
+  if (st->own_stream) (void)hipStreamDestroy(st->own_stream);
+  delete st;
+}
+
+int ohw_state_set_stream(ohw_state* st, void* hip_stream) {
+  return guard([&] {
+    if (!st) throw Error(OHW_E_INVALID_ARG, "state is null");
+    st->stream = hip_stream ? (hipStream_t)hip_stream : st->own_stream;
+  });
+}
+
+int ohw_state_max_batch(const ohw_state* st) { return st ? st->max_batch : 0; }
+
+int ohw_mel(ohw_state* st, const float* pcm, int64_t pcm_stride, const int32_t* n_samples, int batch, int pcm_on_device,
+            int mel_mode, float* mel_out) {
+  return guard([&] {
+    if (!st || !pcm || !n_samples) throw Error(OHW_E_INVALID_ARG, "null argument");
+    if (batch < 1 || batch > st->max_batch) throw Error(OHW_E_INVALID_ARG, "batch exceeds the state's max_batch");
+    if (mel_mode != OHW_MEL_REFLECT && mel_mode != OHW_MEL_ZERO_TAIL) throw Error(OHW_E_INVALID_ARG, "bad mel_mode");
+    HIP_CHECK(hipSetDevice(st->ctx->device));
+    hipStream_t s = st->stream;
+    for (int b = 0; b < batch; ++b)
+      if (n_samples[b] < 0 || n_samples[b] > CHUNK_SAMPLES || n_samples[b] > pcm_stride)
+        throw Error(OHW_E_INVALID_ARG, "n_samples must be in 0..480000 and <= pcm_stride");
+    HIP_CHECK(hipMemcpyAsync(st->n_samples.p, n_samples, (size_t)batch * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipEventRecord(st->ev[0], s));
+    const float* pcm_dev = pcm;
+    int64_t stride = pcm_stride;
+    if (!pcm_on_device) {
+      for (int b = 0; b < batch; ++b)
+        if (n_samples[b] > 0)
+          HIP_CHECK(hipMemcpyAsync(st->pcm.as<float>() + (int64_t)b * CHUNK_SAMPLES, pcm + (int64_t)b * pcm_stride,
+                                   (size_t)n_samples[b] * 4, hipMemcpyHostToDevice, s));
+      pcm_dev = st->pcm.as<float>();
+      stride = CHUNK_SAMPLES;
+    }
+    Dispatch::run(st->ctx->dtype, [&](auto* tag) {
+      using T = std::remove_pointer_t<decltype(tag)>;
+      run_mel<T>(st, pcm_dev, stride, batch, mel_mode);
+    });
+    HIP_CHECK(hipEventRecord(st->ev[1], s));
+    st->enc_batch = batch;
+    if (mel_out) {
+      HIP_CHECK(hipMemcpyAsync(mel_out, st->logmel.p, (size_t)batch * st->ctx->hp.n_mels * CHUNK_FRAMES * 4, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+    }
+  });
+}
+
+int ohw_encode(ohw_state* st, int batch) {
+  return guard([&] {
+    if (!st) throw Error(OHW_E_INVALID_ARG, "state is null");
+    if (batch < 1 || batch != st->enc_batch) throw Error(OHW_E_INVALID_ARG, "encode: batch must equal the batch of the last ohw_mel");
+    HIP_CHECK(hipSetDevice(st->ctx->device));
+    HIP_CHECK(hipEventRecord(st->ev[2], st->stream));
+    Dispatch::run(st->ctx->dtype, [&](auto* tag) {
+      using T = std::remove_pointer_t<decltype(tag)>;
+      run_encode<T>(st, batch);
+    });
+    HIP_CHECK(hipEventRecord(st->ev[3], st->stream));
+  });
+}
+
+int ohw_decode(ohw_state* st, const int32_t* tokens, int n_new, const int32_t* n_past, int batch, float* logits_out) {
+  return guard([&] {
+    if (!st || !tokens || !n_past) throw Error(OHW_E_INVALID_ARG, "null argument");
+    if (batch < 1 || batch != st->enc_batch) throw Error(OHW_E_INVALID_ARG, "decode: batch must equal the batch of the last ohw_encode");
+    if (n_new < 1 || n_new > 8) throw Error(OHW_E_INVALID_ARG, "decode: n_new must be in 1..8");
+    const ohw_hparams& hp = st->ctx->hp;
+    for (int b = 0; b < batch; ++b) {
+      if (n_past[b] < 0 || n_past[b] + n_new > hp.n_text_ctx) throw Error(OHW_E_INVALID_ARG, "decode: position exceeds n_text_ctx");
+      for (int i = 0; i < n_new; ++i)
+        if (tokens[b * n_new + i] < 0 || tokens[b * n_new + i] >= hp.n_vocab) throw Error(OHW_E_INVALID_ARG, "decode: token id out of range");
+    }
+    HIP_CHECK(hipSetDevice(st->ctx->device));
+    hipStream_t s = st->stream;
+    HIP_CHECK(hipMemcpyAsync(st->step_tok.p, tokens, (size_t)batch * n_new * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(st->n_past.p, n_past, (size_t)batch * 4, hipMemcpyHostToDevice, s));
+    Dispatch::run(st->ctx->dtype, [&](auto* tag) {
+      using T = std::remove_pointer_t<decltype(tag)>;
+      run_decoder_step<T>(st, batch, n_new);
+    });
+    if (logits_out)
+      HIP_CHECK(hipMemcpy2DAsync(logits_out, (size_t)hp.n_vocab * 4, st->logits.p, (size_t)st->logits_ld * 4, (size_t)hp.n_vocab * 4,
+                                 (size_t)batch, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  });
+}
+
+void ohw_default_sample_params(const ohw_ctx* ctx, ohw_sample_params* p) {
+  if (!p) return;
+  p->lang_id = 0; p->translate = 0; p->no_timestamps = 0; p->suppress_blank = 1; p->max_initial_ts = 50;
+  p->n_max = ctx ? ctx->hp.n_text_ctx / 2 - 4 : 220;
+  p->force_len = 0;
+}
+
+int ohw_greedy(ohw_state* st, const ohw_sample_params* sp, int batch, int32_t* tokens_out, int32_t* n_tokens_out, int max_tokens,
+               float* sum_logprob_out) {
+  return guard([&] {
+    if (!st || !sp || !tokens_out || !n_tokens_out) throw Error(OHW_E_INVALID_ARG, "null argument");
+    if (batch < 1 || batch != st->enc_batch) throw Error(OHW_E_INVALID_ARG, "greedy: batch must equal the batch of the last ohw_encode");
+    const ohw_ctx* c = st->ctx;
+    if (sp->lang_id < 0 || sp->lang_id >= c->tok.n_langs) throw Error(OHW_E_INVALID_ARG, "greedy: lang_id out of range");
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = st->stream;
+    int32_t prompt[8];
+    const int n_prompt = build_prompt(c, sp, prompt);
+    const int n_max_raw = sp->force_len > 0 ? sp->force_len : sp->n_max;
+    const int n_max = std::min(std::min(n_max_raw, st->max_tokens), c->hp.n_text_ctx - n_prompt);
+    if (n_max < 1) throw Error(OHW_E_INVALID_ARG, "greedy: n_max < 1");
+    std::vector<int32_t> ptoks((size_t)batch * n_prompt);
+    for (int b = 0; b < batch; ++b) std::memcpy(&ptoks[(size_t)b * n_prompt], prompt, (size_t)n_prompt * 4);
+    HIP_CHECK(hipEventRecord(st->ev[4], s));
+    HIP_CHECK(hipMemcpyAsync(st->step_tok.p, ptoks.data(), ptoks.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemsetAsync(st->n_past.p, 0, (size_t)batch * 4, s));
+    HIP_CHECK(hipMemsetAsync(st->n_cur.p, 0, (size_t)batch * 4, s));
+    HIP_CHECK(hipMemsetAsync(st->done.p, 0, (size_t)batch * 4, s));
+    HIP_CHECK(hipMemsetAsync(st->n_done.p, 0, 16, s));
+    HIP_CHECK(hipMemsetAsync(st->sum_lp.p, 0, (size_t)batch * 4, s));
+    SamplerParams spar;
+    ohw_sample_params eff = *sp;
+    eff.n_max = n_max;
+    if (eff.force_len > 0) eff.force_len = n_max;
+    fill_sampler(st, &eff, batch, &spar);
+    int steps = 0;
+    Dispatch::run(c->dtype, [&](auto* tag) {
+      using T = std::remove_pointer_t<decltype(tag)>;
+      run_decoder_step<T>(st, batch, n_prompt);
+      std::vector<int32_t> np((size_t)batch, n_prompt);
+      HIP_CHECK(hipMemcpyAsync(st->n_past.p, np.data(), np.size() * 4, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipStreamSynchronize(s));  // np is a stack-lifetime source
+      ++steps;
+      int32_t n_done_host = 0;
+      for (int it = 0; it < n_max; ++it) {
+        spar.advance = it > 0 ? 1 : 0;  // account for the single-token step that produced these logits
+        launch_sampler(spar, s);
+        const bool check = sp->force_len > 0 ? (it == n_max - 1) : ((it & 7) == 7 || it == n_max - 1);
+        if (check) {
+          HIP_CHECK(hipMemcpyAsync(&n_done_host, st->n_done.p, 4, hipMemcpyDeviceToHost, s));
+          HIP_CHECK(hipStreamSynchronize(s));
+          if (n_done_host >= batch) break;
+        }
+        if (it == n_max - 1) break;
+        // feed the sampled tokens: step_tok <- next_tok, positions n_past (advanced after the step)
+        HIP_CHECK(hipMemcpyAsync(st->step_tok.p, st->next_tok.p, (size_t)batch * 4, hipMemcpyDeviceToDevice, s));
+        run_decoder_step<T>(st, batch, 1);
+        ++steps;
+      }
+    });
+    HIP_CHECK(hipEventRecord(st->ev[5], s));
+    std::vector<int32_t> toks((size_t)batch * st->max_tokens), ncur((size_t)batch);
+    HIP_CHECK(hipMemcpyAsync(toks.data(), st->tokens.p, toks.size() * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(ncur.data(), st->n_cur.p, ncur.size() * 4, hipMemcpyDeviceToHost, s));
+    if (sum_logprob_out) HIP_CHECK(hipMemcpyAsync(sum_logprob_out, st->sum_lp.p, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int b = 0; b < batch; ++b) {
+      const int n = std::min(ncur[(size_t)b], max_tokens);
+      n_tokens_out[b] = n;
+      std::memcpy(tokens_out + (size_t)b * max_tokens, &toks[(size_t)b * st->max_tokens], (size_t)n * 4);
+    }
+    st->last.decode_steps = steps;
+  });
+}
+
+int ohw_state_timings(ohw_state* st, ohw_timings* t) {
+  return guard([&] {
+    if (!st || !t) throw Error(OHW_E_INVALID_ARG, "null argument");
+    HIP_CHECK(hipSetDevice(st->ctx->device));
+    HIP_CHECK(hipStreamSynchronize(st->stream));
+    auto el = [&](int a, int b) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, st->ev[a], st->ev[b]) != hipSuccess) ms = 0.f;
+      return ms;
+    };
+    st->last.mel_ms = el(0, 1);
+    st->last.encode_ms = el(2, 3);
+    st->last.decode_ms = el(4, 5);
+    st->last.total_ms = st->last.mel_ms + st->last.encode_ms + st->last.decode_ms;
+    *t = st->last;
+  });
+}
+
+int ohw_state_fetch(ohw_state* st, const char* what, int batch, float* out, int64_t out_elems) {
+  return guard([&] {
+    if (!st || !what || !out) throw Error(OHW_E_INVALID_ARG, "null argument");
+    if (batch < 1 || batch > st->enc_batch) throw Error(OHW_E_INVALID_ARG, "fetch: batch exceeds the last encode");
+    const ohw_hparams& hp = st->ctx->hp;
+    HIP_CHECK(hipSetDevice(st->ctx->device));
+    hipStream_t s = st->stream;
+    const int64_t d = hp.n_audio_state, Tn = hp.n_audio_ctx;
+    const std::string w = what;
+    DevBuf tmp;
+    auto need = [&](int64_t n) { if (out_elems < n) throw Error(OHW_E_INVALID_ARG, "fetch: output buffer too small"); };
+    auto from_t = [&](const void* src, int64_t n) {
+      need(n);
+      tmp.alloc((size_t)n * 4);
+      Dispatch::run(st->ctx->dtype, [&](auto* tag) {
+        using T = std::remove_pointer_t<decltype(tag)>;
+        launch_to_f32<T>(src, tmp.as<float>(), n, s);
+      });
+      HIP_CHECK(hipMemcpyAsync(out, tmp.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+    };
+    auto from_f32 = [&](const void* src, int64_t n) {
+      need(n);
+      HIP_CHECK(hipMemcpyAsync(out, src, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+    };
+    if (w == "mel") { from_f32(st->logmel.p, (int64_t)batch * hp.n_mels * CHUNK_FRAMES); return; }
+    if (w == "enc") { from_t(st->enc.p, (int64_t)batch * Tn * d); return; }
+    if (w == "stem" || w == "block0") {
+      if (!st->taps) throw Error(OHW_E_INVALID_ARG, "fetch: taps are kept only for d_model <= 512");
+      from_f32(w == "stem" ? st->tap_stem.p : st->tap_block0.p, (int64_t)batch * Tn * d);
+      return;
+    }
+    if (w == "conv1") {
+      // image rows 1..3000 of every window
+      need((int64_t)batch * CHUNK_FRAMES * d);
+      const int es = 2;
+      tmp.alloc((size_t)batch * CHUNK_FRAMES * d * 4);
+      DevBuf packed;
+      packed.alloc((size_t)batch * CHUNK_FRAMES * d * es);
+      for (int b = 0; b < batch; ++b)
+        HIP_CHECK(hipMemcpyAsync((char*)packed.p + (size_t)b * CHUNK_FRAMES * d * es, (char*)st->c1.p + ((size_t)b * MEL_ROWS + 1) * d * es,
+                                 (size_t)CHUNK_FRAMES * d * es, hipMemcpyDeviceToDevice, s));
+      Dispatch::run(st->ctx->dtype, [&](auto* tag) {
+        using T = std::remove_pointer_t<decltype(tag)>;
+        launch_to_f32<T>(packed.p, tmp.as<float>(), (int64_t)batch * CHUNK_FRAMES * d, s);
+      });
+      HIP_CHECK(hipMemcpyAsync(out, tmp.p, (size_t)batch * CHUNK_FRAMES * d * 4, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      return;
+    }
+    if ((w.rfind("xk", 0) == 0 || w.rfind("xv", 0) == 0) && w.size() > 2) {
+      // head-major [B][H][T][64] of layer l -> [B][T][d] on the host
+      const int l = std::atoi(w.c_str() + 2);
+      if (l < 0 || l >= hp.n_text_layer) throw Error(OHW_E_INVALID_ARG, "fetch: layer out of range");
+      const int H = hp.n_text_head;
+      const int64_t slab = (int64_t)st->enc_batch * H * Tn * 64;
+      const int64_t n = (int64_t)batch * H * Tn * 64;
+      need(n);
+      std::vector<float> hm((size_t)n);
+      tmp.alloc((size_t)n * 4);
+      const int which = w[1] == 'k' ? 0 : 1;
+      Dispatch::run(st->ctx->dtype, [&](auto* tag) {
+        using T = std::remove_pointer_t<decltype(tag)>;
+        launch_to_f32<T>((const T*)st->xkv.p + (int64_t)(2 * l + which) * slab, tmp.as<float>(), n, s);
+      });
+      HIP_CHECK(hipMemcpyAsync(hm.data(), tmp.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      for (int b = 0; b < batch; ++b)
+        for (int h = 0; h < H; ++h)
+          for (int64_t t = 0; t < Tn; ++t)
+            std::memcpy(out + ((int64_t)b * Tn + t) * (H * 64) + h * 64, &hm[(size_t)((((int64_t)b * H + h) * Tn + t) * 64)], 64 * 4);
+      return;
+    }
+    throw Error(OHW_E_INVALID_ARG, std::string("fetch: unknown activation '") + what + "'");
+  });
+}
+
+int ohw_dbg_gemm(int dtype, const void* A, const void* W, const float* bias, void* out, int64_t M, int64_t N, int64_t K, int epilogue,
+                 void* stream) {
+  return guard([&] {
+    GemmParams g{};
+    g.A = A; g.W = W; g.bias = bias; g.out = out; g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.a_batch_stride = 0; g.rows_per_batch = M; g.ldc = N; g.c_batch_stride = 0;
+    if (epilogue != EPI_BIAS_T && epilogue != EPI_BIAS_GELU_T && epilogue != EPI_BIAS_RESID_F32 && epilogue != EPI_F32)
+      throw Error(OHW_E_INVALID_ARG, "dbg_gemm: epilogue must be 0, 1, 2 or 4");
+    Dispatch::run(dtype, [&](auto* tag) {
+      using T = std::remove_pointer_t<decltype(tag)>;
+      launch_gemm<T>(g, epilogue, (hipStream_t)stream);
+    });
+  });
+}
+
+int ohw_dbg_attention(int dtype, const void* qkv, void* out, int batch, int T, int n_head, void* stream) {
+  return guard([&] {
+    Dispatch::run(dtype, [&](auto* tag) {
+      using TT = std::remove_pointer_t<decltype(tag)>;
+      launch_encoder_attention<TT>(qkv, out, batch, T, n_head, (hipStream_t)stream);
+    });
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,227 @@
+// gemm.hip — 128x128x64 LDS-tiled MFMA GEMM for the encoder / cross-KV projections (gfx950).
+//
+// C[M][N] = A[M][K] * W[N][K]^T, both operands K-contiguous 16-bit (bf16 or f16), fp32 accumulate.
+// MFMA v_mfma_f32_16x16x32 with SWAPPED operands: the MFMA "A" operand is the weight tile (rows = n),
+// the "B" operand the activation tile (cols = m), so D[n][m] leaves each lane holding 4 consecutive n
+// of ONE output row m; the four n-subtiles of a wave are interleaved (LDS row permutation at staging
+// time) so a lane ends up with 16 contiguous n = 32 B (16-bit out) / 64 B (fp32 out) per row: wide,
+// line-filling epilogue stores.
+//
+// Work split: 256 threads = 4 waves (2 along m x 2 along n), each wave a 64x64 output tile
+// (4x4 MFMA tiles, 64 accumulator VGPRs).  LDS: 2 stages x (128x64 A + 128x64 W) x 2 B = 64 KiB,
+// 16-byte chunks XOR-swizzled by (row & 7) so every ds_read_b128 fragment read is conflict-free.
+// Global -> LDS goes through registers (loads of tile k+1 are issued before the MFMAs of tile k and
+// written to the other LDS stage afterwards: one barrier per K-step).
+// Roofline: MFMA-bound (arithmetic intensity = 64 flop/B at this tile).
+#include "gemm.hpp"
+
+namespace ohw {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int GEMM_THREADS = 256;
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
+  using Ops = TypeOps<T>;
+  using vec8 = typename Ops::vec8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // stage s: A tile at s*32768, W tile at s*32768 + 16384
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const unsigned n_tiles_n = (unsigned)(p.N / BN);
+  const unsigned n_tiles_m = (unsigned)((p.M + BM - 1) / BM);
+  const unsigned nwg = n_tiles_n * n_tiles_m;
+  const unsigned lid = xcd_remap(blockIdx.x, nwg);
+  const int64_t m0 = (int64_t)(lid / n_tiles_n) * BM;
+  const int64_t n0 = (int64_t)(lid % n_tiles_n) * BN;
+
+  const T* __restrict__ A = (const T*)p.A;
+  const T* __restrict__ W = (const T*)p.W;
+
+  // ---- staging assignment: thread -> 4 rows x one 16-byte chunk, for each operand ----
+  const int srow = tid >> 3;  // 0..31 (+32*i)
+  const int chunk = tid & 7;
+  const T* a_ptr[4];
+  const T* w_ptr[4];
+  int a_lds[4], w_lds[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = srow + 32 * i;
+    int64_t m = m0 + r;
+    if (m > p.M - 1) m = p.M - 1;
+    const int64_t b = m / p.rows_per_batch, rr = m % p.rows_per_batch;
+    a_ptr[i] = A + b * p.a_batch_stride + rr * p.lda + chunk * 8;
+    a_lds[i] = r * 128 + ((chunk ^ (r & 7)) << 4);
+    w_ptr[i] = W + (n0 + r) * p.K + chunk * 8;
+    // LDS row permutation inside each 64-row half: n_local = q*16 + ni*4 + j  ->  rho = ni*16 + q*4 + j
+    const int nl = r & 63;
+    const int rho = (r & 64) + (((nl >> 2) & 3) << 4) + ((nl >> 4) << 2) + (nl & 3);
+    w_lds[i] = 16384 + rho * 128 + ((chunk ^ (rho & 7)) << 4);
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[4], rw[4];
+  const int KT = (int)(p.K / BK);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ra[i] = *(const u32x4*)(a_ptr[i]);
+    rw[i] = *(const u32x4*)(w_ptr[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *(u32x4*)(smem + a_lds[i]) = ra[i];
+    *(u32x4*)(smem + w_lds[i]) = rw[i];
+  }
+  __syncthreads();
+
+  // fragment read addresses (within a stage)
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_rd[4], w_rd[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ar = wm * 64 + i * 16 + fr;
+    a_rd[i] = ar * 128;  // chunk applied per k-substep
+    const int wr = wn * 64 + i * 16 + fr;
+    w_rd[i] = 16384 + wr * 128;
+  }
+  const int sw = fr & 7;  // (row & 7) == (fr & 7) for every tile row used above
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = (kt & 1) * 32768;
+    const bool more = kt + 1 < KT;
+    if (more) {
+      const int koff = (kt + 1) * BK;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = *(const u32x4*)(a_ptr[i] + koff);
+        rw[i] = *(const u32x4*)(w_ptr[i] + koff);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int coff = ((s * 4 + fq) ^ sw) << 4;
+      vec8 fa[4], fw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = *(const vec8*)(smem + cur + a_rd[i] + coff);
+        fw[i] = *(const vec8*)(smem + cur + w_rd[i] + coff);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Ops::mfma16(fw[ni], fa[mi], acc[mi][ni]);
+    }
+    if (more) {
+      const int nxt = ((kt + 1) & 1) * 32768;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *(u32x4*)(smem + nxt + a_lds[i]) = ra[i];
+        *(u32x4*)(smem + nxt + w_lds[i]) = rw[i];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (fq, fr) holds, for each mi, n = n0 + wn*64 + fq*16 + [0,16) of row m ----
+  const int64_t nb = n0 + wn * 64 + fq * 16;
+  float bias[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bias[j] = p.bias ? p.bias[nb + j] : 0.0f;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int64_t m = m0 + wm * 64 + mi * 16 + fr;
+    if (m >= p.M) continue;
+    float v[16];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[ni * 4 + j] = acc[mi][ni][j] + bias[ni * 4 + j];
+    const int64_t b = m / p.rows_per_batch, rr = m % p.rows_per_batch;
+    if constexpr (EPI == EPI_BIAS_T || EPI == EPI_BIAS_GELU_T) {
+      if constexpr (EPI == EPI_BIAS_GELU_T) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
+      }
+      T* o = (T*)p.out + b * p.c_batch_stride + rr * p.ldc + nb;
+      u32x4 lo, hi;
+      lo.x = pack2<T>(v[0], v[1]); lo.y = pack2<T>(v[2], v[3]); lo.z = pack2<T>(v[4], v[5]); lo.w = pack2<T>(v[6], v[7]);
+      hi.x = pack2<T>(v[8], v[9]); hi.y = pack2<T>(v[10], v[11]); hi.z = pack2<T>(v[12], v[13]); hi.w = pack2<T>(v[14], v[15]);
+      *(u32x4*)o = lo;
+      *(u32x4*)(o + 8) = hi;
+    } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
+      float* o = (float*)p.out + b * p.c_batch_stride + rr * p.ldc + nb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 old = *(const f32x4*)(o + 4 * j);
+        old.x += v[4 * j]; old.y += v[4 * j + 1]; old.z += v[4 * j + 2]; old.w += v[4 * j + 3];
+        *(f32x4*)(o + 4 * j) = old;
+      }
+    } else if constexpr (EPI == EPI_GELU_POS_F32) {
+      float* o = (float*)p.out + b * p.c_batch_stride + rr * p.ldc + nb;
+      const float* ps = p.pos + rr * p.N + nb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 pp = *(const f32x4*)(ps + 4 * j);
+        f32x4 r;
+        r.x = gelu_erf(v[4 * j]) + pp.x; r.y = gelu_erf(v[4 * j + 1]) + pp.y;
+        r.z = gelu_erf(v[4 * j + 2]) + pp.z; r.w = gelu_erf(v[4 * j + 3]) + pp.w;
+        *(f32x4*)(o + 4 * j) = r;
+      }
+    } else if constexpr (EPI == EPI_F32) {
+      float* o = (float*)p.out + b * p.c_batch_stride + rr * p.ldc + nb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(o + 4 * j) = (f32x4){v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
+    } else if constexpr (EPI == EPI_CROSSKV_T) {
+      // n -> slab (layer*2 + k/v), head, dh ; out[slab][b][h][t][64]
+      const int64_t slab = nb / p.d_model, rem = nb % p.d_model;
+      const int64_t h = rem >> 6, dh = rem & 63;
+      T* o = (T*)p.out + ((((slab * p.batch + b) * p.n_head + h) * p.t_len + rr) << 6) + dh;
+      u32x4 lo, hi;
+      lo.x = pack2<T>(v[0], v[1]); lo.y = pack2<T>(v[2], v[3]); lo.z = pack2<T>(v[4], v[5]); lo.w = pack2<T>(v[6], v[7]);
+      hi.x = pack2<T>(v[8], v[9]); hi.y = pack2<T>(v[10], v[11]); hi.z = pack2<T>(v[12], v[13]); hi.w = pack2<T>(v[14], v[15]);
+      *(u32x4*)o = lo;
+      *(u32x4*)(o + 8) = hi;
+    }
+  }
+}
+
+template <typename T, int EPI>
+static void launch_one(const GemmParams& p, hipStream_t stream) {
+  const unsigned nwg = (unsigned)((p.N / BN) * ((p.M + BM - 1) / BM));
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<T, EPI>), dim3(nwg), dim3(GEMM_THREADS), 65536, stream, p);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void launch_gemm(const GemmParams& p, int epilogue, hipStream_t stream) {
+  if (p.M <= 0) return;
+  if (p.N % BN != 0 || p.K % BK != 0 || p.lda % 8 != 0 || p.a_batch_stride % 8 != 0 || p.rows_per_batch <= 0)
+    throw Error(OHW_E_INVALID_ARG, "gemm: N must be a multiple of 128, K of 64, row strides of 8 elements");
+  switch (epilogue) {
+    case EPI_BIAS_T: launch_one<T, EPI_BIAS_T>(p, stream); break;
+    case EPI_BIAS_GELU_T: launch_one<T, EPI_BIAS_GELU_T>(p, stream); break;
+    case EPI_BIAS_RESID_F32: launch_one<T, EPI_BIAS_RESID_F32>(p, stream); break;
+    case EPI_GELU_POS_F32: launch_one<T, EPI_GELU_POS_F32>(p, stream); break;
+    case EPI_F32: launch_one<T, EPI_F32>(p, stream); break;
+    case EPI_CROSSKV_T: launch_one<T, EPI_CROSSKV_T>(p, stream); break;
+    default: throw Error(OHW_E_INVALID_ARG, "gemm: unknown epilogue");
+  }
+}
+
+template void launch_gemm<bf16_t>(const GemmParams&, int, hipStream_t);
+template void launch_gemm<f16_t>(const GemmParams&, int, hipStream_t);
+
+}  // namespace ohw

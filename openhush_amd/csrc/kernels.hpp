@@ -1,0 +1,87 @@
+// kernels.hpp — launchers of the non-GEMM kernels of the hot path (gfx950).
+#pragma once
+#include "common.hpp"
+
+namespace ohw {
+
+// ---- weights (weights.hip) ---------------------------------------------------------------------
+// dst[i] = value of the procedural generator (openhush_amd/synth.py) for flat index i
+void launch_synth_fill(float* dst, int64_t n, uint32_t key, float scale, float offset, int round_f16, hipStream_t s);
+void launch_f16_to_f32(const void* src_f16, float* dst, int64_t n, hipStream_t s);
+// plain row-major convert: dst T [rows][cols] (dst row stride ld_dst) from src f32 [rows][cols]
+template <typename T> void launch_convert_rows(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_dst, hipStream_t s);
+// conv weight [d_out][c_in][3] f32 -> T [d_out][3][c_pad]
+template <typename T> void launch_repack_conv(const float* src, void* dst, int64_t d_out, int64_t c_in, int64_t c_pad, hipStream_t s);
+// decoder linear [N][K] f32 -> MFMA-fragment tiles T [Npad/16][K/32][64][8], rows >= N zero
+template <typename T> void launch_repack_tiled(const float* src, void* dst, int64_t N, int64_t n_pad, int64_t K, hipStream_t s);
+
+// ---- front end (mel.hip) -----------------------------------------------------------------------
+struct MelParams {
+  const float* pcm;         // device [batch][pcm_stride]
+  int64_t pcm_stride;
+  const int32_t* n_samples; // device [batch]
+  const float* filters;     // device [n_mels][201]
+  const float* twiddle;     // device [2][400]: cos, sin of 2*pi*i/400
+  const float* window;      // device [400] periodic Hann
+  float* logmel;            // device [batch][n_mels][3000] (log10 power, then normalised in place)
+  int32_t* max_bits;        // device [batch] ordered-int running max
+  void* mel_t;              // device T [batch][3002][128] time-major image for conv1
+  int32_t n_mels, batch, mode;
+};
+template <typename T> void launch_mel(const MelParams& p, hipStream_t s);
+
+// ---- normalisation (misc.hip) --------------------------------------------------------------------
+template <typename T> void launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int64_t rows, int d, hipStream_t s);
+template <typename T> void launch_to_f32(const void* src, float* dst, int64_t n, hipStream_t s);
+
+// ---- decoder step (decode.hip) ---------------------------------------------------------------------
+enum DecEpilogue {
+  DEPI_QKV = 0,        // n < d: q T [M][d]; d <= n < 2d: self-K cache; 2d <= n: self-V cache (+bias)
+  DEPI_BIAS_T = 1,     // out T [M][N]
+  DEPI_BIAS_GELU_T = 2,
+  DEPI_BIAS_RESID = 3, // x f32 [M][N] += v + bias
+  DEPI_LOGITS = 4      // logits f32 [batch][ld_logits], only rows m with (m % n_new) == n_new - 1
+};
+struct DecGemmParams {
+  const void* x;       // T [M][K]
+  const void* w;       // tiled T [Npad/16][K/32][64][8]
+  const float* bias;   // [N] or nullptr
+  void* out;           // see DecEpilogue
+  int32_t M, N, K, n_new;
+  // DEPI_QKV
+  void* k_cache; void* v_cache;     // T [B][H][n_text_ctx][64] of this layer
+  const int32_t* n_past;            // device [B]
+  int32_t d_model, n_head, n_ctx;
+  int64_t ld_out;
+};
+template <typename T> void launch_dec_gemm(const DecGemmParams& p, int epilogue, hipStream_t s);
+
+// x f32 [M][d] = token_embedding[tok[m]] + pos_emb[n_past[m / n_new] + m % n_new]
+template <typename T> void launch_embed(const void* emb_tiled, const float* pos, const int32_t* tok, const int32_t* n_past,
+                                        float* x, int M, int n_new, int d, hipStream_t s);
+// causal self-attention of the new tokens against the cache.  q T [M][d] -> out T [M][d]
+template <typename T> void launch_self_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* n_past,
+                                            void* out, int M, int n_new, int n_head, int n_ctx, hipStream_t s);
+// cross-attention: q T [M][d]; cross K/V head-major T [B][H][t_len][64] of this layer -> out T [M][d]
+template <typename T> void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out, int M, int n_new,
+                                             int n_head, int t_len, hipStream_t s);
+
+// device-side logits filter + arg-max (restates oracle ref_process_logits)
+struct SamplerParams {
+  const float* logits;   // [batch][ld]
+  int64_t ld;
+  int32_t* tokens;       // [batch][max_tokens] sampled so far
+  int32_t* n_cur;        // [batch]
+  int32_t* n_past;       // [batch]   (advanced by one for live windows)
+  int32_t* next_tok;     // [batch]   token to feed next
+  int32_t* done;         // [batch]
+  int32_t* n_done;       // [1] number of finished windows
+  float* sum_logprob;    // [batch]
+  int32_t batch, max_tokens, n_vocab;
+  int32_t eot, sot, translate, transcribe, solm, prev, nosp, no_ts, ts_begin, blank, n_langs;
+  int32_t suppress_blank, no_timestamps, max_initial_ts, n_max, force_len, n_text_ctx;
+  int32_t advance;       // 1: n_past[b] += 1 first (a single-token step ran since the last call)
+};
+void launch_sampler(const SamplerParams& p, hipStream_t s);
+
+}  // namespace ohw

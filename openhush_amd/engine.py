@@ -1,0 +1,448 @@
+"""ctypes binding of libohw.so and a Python mirror of the reference's `WhisperEngine`.
+
+The product path is the HIP library: nothing here computes; there is no CPU fallback and no import
+of oracle/.  If libohw.so is missing or cannot be loaded this module raises at import of the
+library handle (`lib()`), loudly.
+
+Mirror of the reference interface (reference src/engine/whisper.rs):
+    WhisperEngine.new(model_path, language, translate, use_gpu)   :129-179
+    WhisperEngine.transcribe(AudioBuffer) -> TranscriptionResult  :204-310
+    WhisperEngine.benchmark(safety_margin) -> BenchmarkResult     :334-387
+    WhisperError variants                                          :14-27
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libohw.so")
+
+CHUNK_SAMPLES = 480000
+CHUNK_FRAMES = 3000
+
+OHW_DTYPE_BF16, OHW_DTYPE_F16 = 0, 1
+OHW_MEL_REFLECT, OHW_MEL_ZERO_TAIL = 0, 1
+EPI_BIAS_T, EPI_BIAS_GELU_T, EPI_BIAS_RESID_F32, EPI_F32 = 0, 1, 2, 4
+
+OHW_E_MODEL_NOT_FOUND, OHW_E_LOAD_FAILED, OHW_E_TRANSCRIBE = -3001, -3002, -3003
+OHW_E_NO_GPU, OHW_E_OOM, OHW_E_INVALID_ARG, OHW_E_VALIDATION = -3004, -3005, -3006, -3007
+
+
+class HParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_vocab", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
+                                         "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer", "n_mels", "ftype")]
+
+
+class SpecialTokens(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("eot", "sot", "translate", "transcribe", "solm", "prev", "nosp", "no_timestamps",
+                                         "timestamp_begin", "blank", "n_langs")]
+
+
+class AudioInfo(C.Structure):
+    _fields_ = [("error", C.c_int32), ("duration_secs", C.c_float), ("sample_count", C.c_int64), ("min_value", C.c_float),
+                ("max_value", C.c_float), ("rms", C.c_float), ("nan_count", C.c_int64), ("inf_count", C.c_int64)]
+
+
+class SampleParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("lang_id", "translate", "no_timestamps", "suppress_blank", "max_initial_ts", "n_max", "force_len")]
+
+
+class Timings(C.Structure):
+    _fields_ = [("mel_ms", C.c_float), ("encode_ms", C.c_float), ("decode_ms", C.c_float), ("total_ms", C.c_float), ("decode_steps", C.c_int32)]
+
+
+AUDIO_ERRORS = {0: "Ok", 1: "Empty", 2: "InvalidSampleRate", 3: "TooLong", 4: "TooShort", 5: "ContainsNaN", 6: "ContainsInfinite"}
+
+# every symbol include/ohw.h declares
+EXPORTS = [
+    "ohw_validate_audio", "ohw_ctx_create", "ohw_ctx_create_synthetic", "ohw_ctx_info", "ohw_token_text", "ohw_ctx_free",
+    "ohw_state_create", "ohw_state_free", "ohw_state_set_stream", "ohw_state_max_batch", "ohw_mel", "ohw_encode", "ohw_decode",
+    "ohw_default_sample_params", "ohw_sample_greedy_host", "ohw_greedy", "ohw_state_timings", "ohw_engine_new",
+    "ohw_engine_transcribe", "ohw_engine_last_tokens", "ohw_engine_benchmark", "ohw_engine_free", "ohw_engine_state",
+    "ohw_engine_ctx", "ohw_lang_id_to_code", "ohw_lang_code_to_id", "ohw_last_error", "ohw_abi_version", "ohw_state_fetch",
+    "ohw_dbg_gemm", "ohw_dbg_attention",
+]
+
+
+class WhisperError(RuntimeError):
+    """reference src/engine/whisper.rs:14-27"""
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg)
+        self.code = code
+
+
+class ModelNotFound(WhisperError):
+    pass
+
+
+class LoadFailed(WhisperError):
+    pass
+
+
+class TranscriptionFailed(WhisperError):
+    pass
+
+
+class ValidationFailed(WhisperError):
+    def __init__(self, code: int, msg: str, info: Optional[AudioInfo] = None):
+        super().__init__(code, msg)
+        self.info = info
+        self.kind = AUDIO_ERRORS.get(info.error, "?") if info is not None else "?"
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -m openhush_amd.build` (no fallback path exists)")
+        L = C.CDLL(LIB_PATH)
+        vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        L.ohw_last_error.restype = C.c_char_p
+        L.ohw_lang_id_to_code.restype = C.c_char_p
+        L.ohw_lang_id_to_code.argtypes = [C.c_int32]
+        L.ohw_lang_code_to_id.argtypes = [C.c_char_p]
+        L.ohw_validate_audio.argtypes = [fp, C.c_int64, C.c_uint32, C.POINTER(AudioInfo)]
+        L.ohw_ctx_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+        L.ohw_ctx_create_synthetic.argtypes = [C.POINTER(HParams), C.c_uint32, C.c_int, C.c_int, C.POINTER(vp)]
+        L.ohw_ctx_info.argtypes = [vp, C.POINTER(HParams), C.POINTER(SpecialTokens)]
+        L.ohw_token_text.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p)]
+        L.ohw_ctx_free.argtypes = [vp]
+        L.ohw_ctx_free.restype = None
+        L.ohw_state_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+        L.ohw_state_free.argtypes = [vp]
+        L.ohw_state_free.restype = None
+        L.ohw_state_set_stream.argtypes = [vp, vp]
+        L.ohw_state_max_batch.argtypes = [vp]
+        L.ohw_mel.argtypes = [vp, vp, C.c_int64, ip, C.c_int, C.c_int, C.c_int, fp]
+        L.ohw_encode.argtypes = [vp, C.c_int]
+        L.ohw_decode.argtypes = [vp, ip, C.c_int, ip, C.c_int, fp]
+        L.ohw_default_sample_params.argtypes = [vp, C.POINTER(SampleParams)]
+        L.ohw_default_sample_params.restype = None
+        L.ohw_sample_greedy_host.argtypes = [vp, C.POINTER(SampleParams), fp, ip, C.c_int, fp]
+        L.ohw_greedy.argtypes = [vp, C.POINTER(SampleParams), C.c_int, ip, ip, C.c_int, fp]
+        L.ohw_state_timings.argtypes = [vp, C.POINTER(Timings)]
+        L.ohw_engine_new.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        L.ohw_engine_transcribe.argtypes = [vp, fp, C.c_int64, C.c_uint32, C.c_char_p, C.c_size_t, C.c_char_p,
+                                            C.POINTER(C.c_uint64), C.POINTER(AudioInfo)]
+        L.ohw_engine_last_tokens.argtypes = [vp, C.POINTER(ip), C.POINTER(C.c_int)]
+        L.ohw_engine_benchmark.argtypes = [vp, C.c_float, fp, fp, fp]
+        L.ohw_engine_free.argtypes = [vp]
+        L.ohw_engine_free.restype = None
+        L.ohw_engine_state.argtypes = [vp]
+        L.ohw_engine_state.restype = vp
+        L.ohw_engine_ctx.argtypes = [vp]
+        L.ohw_engine_ctx.restype = vp
+        L.ohw_state_fetch.argtypes = [vp, C.c_char_p, C.c_int, fp, C.c_int64]
+        L.ohw_dbg_gemm.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, vp]
+        L.ohw_dbg_attention.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().ohw_last_error().decode("utf-8", "replace")
+
+
+def _raise(code: int, info: Optional[AudioInfo] = None):
+    msg = last_error()
+    if code == OHW_E_MODEL_NOT_FOUND:
+        raise ModelNotFound(code, msg)
+    if code == OHW_E_VALIDATION:
+        raise ValidationFailed(code, msg, info)
+    if code in (OHW_E_LOAD_FAILED, OHW_E_NO_GPU, OHW_E_OOM):
+        raise LoadFailed(code, msg)
+    raise TranscriptionFailed(code, msg)
+
+
+def _check(code: int):
+    if code != 0:
+        _raise(code)
+
+
+def _fp(a: np.ndarray):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def validate_audio(samples: np.ndarray, sample_rate: int) -> AudioInfo:
+    """validation::validate_audio — raises ValidationFailed with .kind in AUDIO_ERRORS values"""
+    s = np.ascontiguousarray(samples, dtype=np.float32)
+    info = AudioInfo()
+    ptr = _fp(s) if s.size else C.cast(None, C.POINTER(C.c_float))
+    rc = lib().ohw_validate_audio(ptr, s.size, sample_rate, C.byref(info))
+    if rc != 0:
+        raise ValidationFailed(rc, "Audio validation failed: " + AUDIO_ERRORS.get(info.error, "?"), info)
+    return info
+
+
+def lang_id_to_code(i: int) -> str:
+    return lib().ohw_lang_id_to_code(i).decode()
+
+
+def lang_code_to_id(code: str) -> int:
+    return int(lib().ohw_lang_code_to_id(code.encode()))
+
+
+class Context:
+    """ohw_ctx: the model resident in HBM"""
+
+    def __init__(self, handle):
+        self.h = C.c_void_p(handle)
+        self.hp = HParams()
+        self.tok = SpecialTokens()
+        _check(lib().ohw_ctx_info(self.h, C.byref(self.hp), C.byref(self.tok)))
+
+    @classmethod
+    def from_file(cls, path: str, device: int = 0, dtype: int = OHW_DTYPE_BF16) -> "Context":
+        h = C.c_void_p()
+        _check(lib().ohw_ctx_create(path.encode(), device, dtype, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def synthetic(cls, hparams: Sequence[int], seed: int = 1234, device: int = 0, dtype: int = OHW_DTYPE_BF16) -> "Context":
+        hp = HParams(*[int(x) for x in hparams])
+        h = C.c_void_p()
+        _check(lib().ohw_ctx_create_synthetic(C.byref(hp), seed, device, dtype, C.byref(h)))
+        return cls(h.value)
+
+    def default_params(self) -> SampleParams:
+        p = SampleParams()
+        lib().ohw_default_sample_params(self.h, C.byref(p))
+        return p
+
+    def token_text(self, i: int) -> bytes:
+        s = C.c_char_p()
+        n = lib().ohw_token_text(self.h, i, C.byref(s))
+        return s.value[:n] if n else b""
+
+    def sample_greedy_host(self, p: SampleParams, logits: np.ndarray, cur: List[int]) -> Tuple[int, float]:
+        lg = np.ascontiguousarray(logits, dtype=np.float32).copy()
+        c = np.asarray(cur if len(cur) else [0], dtype=np.int32)
+        lp = C.c_float(0)
+        tok = lib().ohw_sample_greedy_host(self.h, C.byref(p), _fp(lg), _ip(c), len(cur), C.byref(lp))
+        return int(tok), float(lp.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ohw_ctx_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class State:
+    """ohw_state: activations + KV caches for up to max_batch 30 s windows"""
+
+    def __init__(self, ctx: Context, max_batch: int = 1):
+        self.ctx = ctx
+        h = C.c_void_p()
+        _check(lib().ohw_state_create(ctx.h, max_batch, C.byref(h)))
+        self.h = h
+        self.max_batch = max_batch
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ohw_state_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr: Optional[int]):
+        _check(lib().ohw_state_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+
+    def mel(self, pcm: np.ndarray, n_samples: Optional[Sequence[int]] = None, mode: int = OHW_MEL_REFLECT, want: bool = True):
+        """pcm: [B][stride] float32 host array"""
+        pcm = np.ascontiguousarray(np.atleast_2d(pcm), dtype=np.float32)
+        B, stride = pcm.shape
+        ns = np.asarray(n_samples if n_samples is not None else [min(stride, CHUNK_SAMPLES)] * B, dtype=np.int32)
+        out = np.empty((B, self.ctx.hp.n_mels, CHUNK_FRAMES), dtype=np.float32) if want else None
+        _check(lib().ohw_mel(self.h, pcm.ctypes.data_as(C.c_void_p), stride, _ip(ns), B, 0, mode,
+                             _fp(out) if want else C.cast(None, C.POINTER(C.c_float))))
+        return out
+
+    def mel_device(self, pcm_ptr: int, stride: int, n_samples: Sequence[int], mode: int = OHW_MEL_REFLECT):
+        """pcm already resident in HBM (e.g. a torch tensor's data_ptr())"""
+        ns = np.asarray(n_samples, dtype=np.int32)
+        _check(lib().ohw_mel(self.h, C.c_void_p(pcm_ptr), stride, _ip(ns), len(ns), 1, mode, C.cast(None, C.POINTER(C.c_float))))
+
+    def encode(self, batch: int):
+        _check(lib().ohw_encode(self.h, batch))
+
+    def decode(self, tokens: np.ndarray, n_past: Sequence[int]) -> np.ndarray:
+        """tokens [B][n_new] -> logits [B][n_vocab] of the last fed position"""
+        t = np.ascontiguousarray(np.atleast_2d(tokens), dtype=np.int32)
+        B, n_new = t.shape
+        npast = np.asarray(n_past, dtype=np.int32)
+        out = np.empty((B, self.ctx.hp.n_vocab), dtype=np.float32)
+        _check(lib().ohw_decode(self.h, _ip(t), n_new, _ip(npast), B, _fp(out)))
+        return out
+
+    def greedy(self, batch: int, p: Optional[SampleParams] = None):
+        """device-resident greedy loop -> (list of token lists, sum_logprob[B])"""
+        p = p or self.ctx.default_params()
+        cap = self.ctx.hp.n_text_ctx
+        toks = np.zeros((batch, cap), dtype=np.int32)
+        nt = np.zeros(batch, dtype=np.int32)
+        slp = np.zeros(batch, dtype=np.float32)
+        _check(lib().ohw_greedy(self.h, C.byref(p), batch, _ip(toks), _ip(nt), cap, _fp(slp)))
+        return [[int(x) for x in toks[b, :nt[b]]] for b in range(batch)], slp
+
+    def greedy_host_sampler(self, batch: int, p: Optional[SampleParams] = None):
+        """the same loop with the HOST owning the sampler: logits cross PCIe every step"""
+        p = p or self.ctx.default_params()
+        ctx = self.ctx
+        prompt = [ctx.tok.sot]
+        if ctx.hp.n_vocab >= 51865:
+            prompt += [ctx.tok.sot + 1 + p.lang_id, ctx.tok.translate if p.translate else ctx.tok.transcribe]
+        if p.no_timestamps:
+            prompt.append(ctx.tok.no_timestamps)
+        n_max = p.force_len if p.force_len > 0 else p.n_max
+        logits = self.decode(np.tile(np.asarray(prompt, np.int32), (batch, 1)), [0] * batch)
+        out = [[] for _ in range(batch)]
+        done = [False] * batch
+        n_past = [len(prompt)] * batch
+        feed = [0] * batch
+        for _ in range(n_max):
+            for b in range(batch):
+                if done[b]:
+                    continue
+                tok, _ = ctx.sample_greedy_host(p, logits[b], out[b])
+                if tok == ctx.tok.eot:
+                    done[b] = True
+                    continue
+                out[b].append(tok)
+                feed[b] = tok
+                if len(out[b]) >= n_max or n_past[b] + 1 >= ctx.hp.n_text_ctx:
+                    done[b] = True
+            if all(done):
+                break
+            logits = self.decode(np.asarray(feed, np.int32).reshape(batch, 1), n_past)
+            n_past = [n + (0 if done[b] else 1) for b, n in enumerate(n_past)]
+        return out
+
+    def timings(self) -> Timings:
+        t = Timings()
+        _check(lib().ohw_state_timings(self.h, C.byref(t)))
+        return t
+
+    def fetch(self, what: str, batch: int) -> np.ndarray:
+        hp = self.ctx.hp
+        d, T = hp.n_audio_state, hp.n_audio_ctx
+        shape = {"mel": (batch, hp.n_mels, CHUNK_FRAMES), "conv1": (batch, CHUNK_FRAMES, d)}.get(what, (batch, T, d))
+        out = np.empty(shape, dtype=np.float32)
+        _check(lib().ohw_state_fetch(self.h, what.encode(), batch, _fp(out), out.size))
+        return out
+
+
+# ---- mirror of the reference's engine types ------------------------------------------------------
+@dataclasses.dataclass
+class AudioBuffer:
+    """reference src/input/audio.rs:55-61"""
+    samples: np.ndarray
+    sample_rate: int = 16000
+
+    def duration_secs(self) -> float:
+        return len(self.samples) / float(self.sample_rate)
+
+
+@dataclasses.dataclass
+class TranscriptionResult:
+    """reference src/engine/whisper.rs:30-40"""
+    text: str
+    language: str
+    duration_ms: int
+
+
+@dataclasses.dataclass
+class BenchmarkResult:
+    """reference src/engine/whisper.rs:314-323"""
+    overhead_secs: float
+    recommended_chunk_interval: float
+    test_audio_secs: float
+
+
+class WhisperEngine:
+    """Drop-in mirror of the reference's WhisperEngine over libohw.so."""
+
+    def __init__(self, handle):
+        self.h = handle
+        self.ctx_h = C.c_void_p(lib().ohw_engine_ctx(self.h))
+        self.state_h = C.c_void_p(lib().ohw_engine_state(self.h))
+
+    @classmethod
+    def new(cls, model_path: str, language: str, translate: bool, use_gpu: bool, device: int = 0,
+            dtype: int = OHW_DTYPE_BF16, max_batch: int = 1) -> "WhisperEngine":
+        h = C.c_void_p()
+        rc = lib().ohw_engine_new(str(model_path).encode(), language.encode(), int(translate), int(use_gpu), device, dtype,
+                                  max_batch, C.byref(h))
+        if rc != 0:
+            _raise(rc)
+        return cls(h)
+
+    def transcribe(self, audio: AudioBuffer) -> TranscriptionResult:
+        s = np.ascontiguousarray(audio.samples, dtype=np.float32)
+        buf = C.create_string_buffer(1 << 16)
+        lang = C.create_string_buffer(8)
+        ms = C.c_uint64(0)
+        info = AudioInfo()
+        ptr = _fp(s) if s.size else C.cast(None, C.POINTER(C.c_float))
+        rc = lib().ohw_engine_transcribe(self.h, ptr, s.size, audio.sample_rate, buf, len(buf), lang, C.byref(ms), C.byref(info))
+        if rc != 0:
+            _raise(rc, info)
+        return TranscriptionResult(buf.value.decode("utf-8", "replace"), lang.value.decode(), int(ms.value))
+
+    def last_tokens(self) -> List[int]:
+        p = C.POINTER(C.c_int32)()
+        n = C.c_int(0)
+        lib().ohw_engine_last_tokens(self.h, C.byref(p), C.byref(n))
+        return [int(p[i]) for i in range(n.value)]
+
+    def benchmark(self, safety_margin: float) -> BenchmarkResult:
+        a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
+        _check(lib().ohw_engine_benchmark(self.h, safety_margin, C.byref(a), C.byref(b), C.byref(c)))
+        return BenchmarkResult(a.value, b.value, c.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ohw_engine_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- model names: reference src/engine/whisper.rs:43-103 -----------------------------------------
+_MODEL_FILES = {"tiny": "ggml-tiny.bin", "base": "ggml-base.bin", "small": "ggml-small.bin", "medium": "ggml-medium.bin",
+                "large-v3": "ggml-large-v3.bin"}
+_MODEL_ALIASES = {"large": "large-v3", "largev3": "large-v3"}
+
+
+def model_filename(name: str) -> str:
+    """WhisperModel::from_str + filename(): raises KeyError for names the reference rejects (e.g. 'tiny.en')"""
+    key = name.lower()
+    key = _MODEL_ALIASES.get(key, key)
+    return _MODEL_FILES[key]

@@ -1,0 +1,255 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the committed goldens.
+
+Tolerances (stated once, used below):
+  mel      fp32 both sides                          : 2e-4 abs on the normalised log-mel
+  encoder  16-bit GEMM operands, fp32 accumulate    : bf16 6e-2 / f16 8e-3 abs on O(1) activations
+  logits   sigma ~ 4                                : bf16 0.25 / f16 0.03 abs
+  tokens   greedy: identical, except where the oracle's own top-2 margin is below the logit tolerance
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from openhush_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+TOL_ACT = {0: 6e-2, 1: 8e-3}
+TOL_LOGIT = {0: 0.25, 1: 0.03}
+
+
+@pytest.fixture(scope="module")
+def E():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible")
+    from openhush_amd import engine
+    engine.lib()
+    return engine
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+    return o
+
+
+@pytest.fixture(scope="module", params=["micro", "micro-v3"])
+def preset(request):
+    return request.param
+
+
+@pytest.fixture(scope="module")
+def models(E, oracle, tmp_models, preset):
+    path = tmp_models(preset)
+    om = oracle.Model.load(path)
+    ctxs = {dt: E.Context.from_file(path, 0, dt) for dt in (0, 1)}
+    return preset, path, om, ctxs
+
+
+def _pcm_batch():
+    a = synth.synth_audio(7)
+    b = np.zeros(synth.CHUNK_SAMPLES, np.float32)
+    b[:48000] = synth.synth_audio(3, 48000)
+    c = synth.synth_audio(11)
+    return np.stack([a, b, c]), [synth.CHUNK_SAMPLES, 48000, synth.CHUNK_SAMPLES]
+
+
+def test_mel_matches_oracle_and_golden(E, models):
+    preset, _, om, ctxs = models
+    g = np.load(os.path.join(GOLDEN, f"{preset}.npz"))
+    pcm, ns = _pcm_batch()
+    st = E.State(ctxs[0], 3)
+    for mode in (E.OHW_MEL_REFLECT, E.OHW_MEL_ZERO_TAIL):
+        mel = st.mel(pcm, ns, mode)
+        for b in range(3):
+            ref = om.log_mel(pcm[b, :ns[b]], mode)
+            assert np.abs(mel[b] - ref).max() < 2e-4, (mode, b)
+    mel = st.mel(pcm, ns, E.OHW_MEL_REFLECT)
+    assert np.abs(mel[0][:, ::10] - g["mel_b_sub"]).max() < 3e-4
+    assert np.abs(mel[1][:, ::10] - g["mel_a_sub"]).max() < 3e-4
+    assert np.abs(mel[0][:, -4:] - g["mel_b_last"]).max() < 3e-4
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_encoder_matches_oracle(E, models, dt):
+    preset, _, om, ctxs = models
+    pcm, ns = _pcm_batch()
+    st = E.State(ctxs[dt], 3)
+    mel = st.mel(pcm, ns, E.OHW_MEL_REFLECT)
+    st.encode(3)
+    tol = TOL_ACT[dt]
+    conv1, stem, block0, enc = (st.fetch(k, 3) for k in ("conv1", "stem", "block0", "enc"))
+    g = np.load(os.path.join(GOLDEN, f"{preset}.npz"))
+    for b in range(3):
+        r_enc, r_c1, r_stem, r_b0 = om.encode(mel[b], taps=True)
+        assert np.abs(conv1[b] - r_c1).max() < tol
+        assert np.abs(stem[b] - r_stem).max() < tol
+        assert np.abs(block0[b] - r_b0).max() < 2 * tol
+        assert np.abs(enc[b] - r_enc).max() < 2 * tol
+    # golden (transformers) directly
+    assert np.abs(enc[0][::10] - g["enc_b_sub"]).max() < 2 * tol
+    assert np.abs(enc[1][::10] - g["enc_a_sub"]).max() < 2 * tol
+    L = ctxs[dt].hp.n_text_layer
+    xk0 = st.fetch("xk0", 3)
+    xvl = st.fetch(f"xv{L - 1}", 3)
+    assert np.abs(xk0[0][::25] - g["xk0_b_sub"]).max() < 2 * tol
+    assert np.abs(xvl[1][::25] - g["xvl_a_sub"]).max() < 2 * tol
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_teacher_forced_logits(E, oracle, models, dt):
+    preset, _, om, ctxs = models
+    g = np.load(os.path.join(GOLDEN, f"{preset}.npz"))
+    forced = [int(t) for t in g["forced_tokens"]]
+    pcm, ns = _pcm_batch()
+    st = E.State(ctxs[dt], 3)
+    mel = st.mel(pcm, ns, E.OHW_MEL_REFLECT)
+    st.encode(3)
+    ost = []
+    for b in range(3):
+        s = oracle.State(om)
+        s.set_encoder_output(om.encode(mel[b]))
+        ost.append(s)
+    ref_all = [s.decode(forced, 0, all_pos=True) for s in ost]
+    tol = TOL_LOGIT[dt]
+    # prompt of 4 tokens in one call, then one token per call with ragged positions unchanged
+    lg = st.decode(np.tile(np.asarray(forced[:4], np.int32), (3, 1)), [0, 0, 0])
+    for b in range(3):
+        assert np.abs(lg[b] - ref_all[b][3]).max() < tol
+    worst = 0.0
+    for i in range(4, len(forced)):
+        lg = st.decode(np.full((3, 1), forced[i], np.int32), [i, i, i])
+        for b in range(3):
+            worst = max(worst, float(np.abs(lg[b] - ref_all[b][i]).max()))
+            assert lg[b].argmax() == ref_all[b][i].argmax() or np.sort(ref_all[b][i])[-1] - np.sort(ref_all[b][i])[-2] < 2 * tol
+    assert worst < tol, worst
+    # window 0 against the transformers golden columns
+    cols = g["logit_cols"]
+    assert np.abs(lg[0][cols] - g["logits_b_cols"][-1]).max() < tol
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_greedy_tokens_match_oracle(E, oracle, models, dt):
+    _, _, om, ctxs = models
+    pcm, ns = _pcm_batch()
+    st = E.State(ctxs[dt], 3)
+    mel = st.mel(pcm, ns, E.OHW_MEL_REFLECT)
+    st.encode(3)
+    p = ctxs[dt].default_params()
+    p.n_max = 40
+    dev_tokens, slp = st.greedy(3, p)
+    host_tokens = st.greedy_host_sampler(3, p)
+    op = om.default_params()
+    op.n_max = 40
+    tol = TOL_LOGIT[dt]
+    for b in range(3):
+        s = oracle.State(om)
+        s.set_encoder_output(om.encode(mel[b]))
+        ref, lps, margins, _ = s.greedy(op)
+        for name, got in (("device", dev_tokens[b]), ("host", host_tokens[b])):
+            n = min(len(ref), len(got))
+            div = next((i for i in range(n) if ref[i] != got[i]), None)
+            if div is None:
+                assert len(ref) == len(got) or margins[n] < 2 * tol, (name, b, len(ref), len(got))
+            else:
+                # a divergence is legitimate only at a near-tie of the oracle itself
+                assert margins[div] < 2 * tol, (name, b, div, margins[div], ref[:div + 1], got[:div + 1])
+        assert dev_tokens[b] == host_tokens[b], b
+        if dev_tokens[b] == ref:
+            assert abs(slp[b] - float(lps.sum())) < 0.05 * max(1, len(ref))
+
+
+def test_force_len_and_batch_invariance(E, models):
+    _, _, _, ctxs = models
+    ctx = ctxs[0]
+    pcm, ns = _pcm_batch()
+    p = ctx.default_params()
+    p.force_len = 24
+    st3 = E.State(ctx, 3)
+    st3.mel(pcm, ns, E.OHW_MEL_ZERO_TAIL, want=False)
+    st3.encode(3)
+    t3, _ = st3.greedy(3, p)
+    assert [len(t) for t in t3] == [24, 24, 24]
+    assert all(tok != ctx.tok.eot for t in t3 for tok in t)
+    st1 = E.State(ctx, 1)
+    for b in range(3):
+        st1.mel(pcm[b:b + 1], ns[b:b + 1], E.OHW_MEL_ZERO_TAIL, want=False)
+        st1.encode(1)
+        t1, _ = st1.greedy(1, p)
+        assert t1[0] == t3[b], b   # a window's result does not depend on its batch neighbours
+
+
+def test_synthetic_context_equals_file_context(E, models):
+    preset, _, _, ctxs = models
+    syn = E.Context.synthetic(synth.PRESETS[preset].as_list(), 1234, 0, 0)
+    pcm, ns = _pcm_batch()
+    outs = []
+    for ctx in (ctxs[0], syn):
+        st = E.State(ctx, 1)
+        st.mel(pcm[:1], ns[:1], E.OHW_MEL_REFLECT, want=False)
+        st.encode(1)
+        outs.append(st.decode(np.asarray([[ctx.tok.sot, ctx.tok.sot + 1, ctx.tok.transcribe]], np.int32), [0]))
+    assert np.array_equal(outs[0], outs[1])
+    assert (syn.tok.eot, syn.tok.timestamp_begin, syn.tok.blank) == (ctxs[0].tok.eot, ctxs[0].tok.timestamp_begin, ctxs[0].tok.blank)
+
+
+def test_whisper_engine_mirror(E, oracle, models):
+    preset, path, om, _ = models
+    eng = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_F16, 2)
+    # 70 s -> three host-side 30 s windows (2 + 1 batches)
+    pcm = np.concatenate([synth.synth_audio(21), synth.synth_audio(22), synth.synth_audio(23, 160000)])
+    res = eng.transcribe(E.AudioBuffer(pcm, 16000))
+    assert res.language == "en" and res.duration_ms >= 0
+    toks = eng.last_tokens()
+    ref = []
+    for w in range(3):
+        t, _ = om.transcribe_chunk(pcm[w * 480000:(w + 1) * 480000], None, 1)
+        ref += t
+    # f16 path: expect equality; tolerate a divergence only if the decode lengths say a near-tie flipped
+    if toks != ref:
+        n = min(len(toks), len(ref))
+        agree = sum(1 for i in range(n) if toks[i] == ref[i])
+        assert agree >= 0.9 * n, (agree, n)
+    text = b"".join(E.Context.token_text(_Ctx(eng), t) for t in toks if t < 50257)
+    assert res.text == text.decode().strip()
+    # validation errors surface as ValidationFailed with the reference's variant
+    with pytest.raises(E.ValidationFailed) as ei:
+        eng.transcribe(E.AudioBuffer(np.zeros(800, np.float32), 16000))
+    assert ei.value.kind == "TooShort"
+    with pytest.raises(E.ValidationFailed) as ei:
+        eng.transcribe(E.AudioBuffer(np.zeros(44100, np.float32), 44100))
+    assert ei.value.kind == "InvalidSampleRate"
+    # 2 s of silence: what benchmark() transcribes (reference src/engine/whisper.rs:341-353)
+    bm = eng.benchmark(0.2)
+    assert bm.test_audio_secs == 2.0 and bm.overhead_secs >= 0.001
+    assert abs(bm.recommended_chunk_interval - bm.overhead_secs * 1.2) < 1e-6
+    eng.close()
+    # create / destroy cycles (idle-unload / lazy-load, reference src/daemon.rs:2242-2283)
+    for _ in range(2):
+        e2 = E.WhisperEngine.new(path, "de", True, True, 0, E.OHW_DTYPE_BF16, 1)
+        r = e2.transcribe(E.AudioBuffer(synth.synth_audio(5, 32000), 16000))
+        assert r.language == "de"
+        e2.close()
+
+
+class _Ctx:
+    """borrowed (non-owning) view of an engine's context for token_text"""
+    def __init__(self, eng):
+        self.h = eng.ctx_h
+
+
+def test_engine_error_paths(E, tmp_path):
+    with pytest.raises(E.ModelNotFound) as ei:
+        E.WhisperEngine.new(str(tmp_path / "ggml-small.bin"), "auto", False, True)
+    assert "openhush model download small" in str(ei.value)
+    bad = tmp_path / "ggml-bad.bin"
+    bad.write_bytes(b"not a model")
+    with pytest.raises(E.LoadFailed):
+        E.WhisperEngine.new(str(bad), "auto", False, True)
+    with pytest.raises(E.LoadFailed) as ei:
+        E.WhisperEngine.new(str(bad), "auto", False, False)   # device = "cpu": no CPU path exists
+    assert ei.value.code == E.OHW_E_NO_GPU
