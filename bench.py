@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the Whisper hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the whole path over one batch of synthetic 30 s windows per GPU:
+log-mel -> encoder -> cross K/V -> greedy decode (EOT suppressed, exactly --tokens tokens per window,
+SURVEY.md 8d) with the PCM already resident in HBM.  Workload at every N: large-v3 dimensions,
+--batch windows per GPU (weak scaling: independent windows, no data-path collective; the only
+communication is the gather of token ids to rank 0 after each step).
+
+    python bench.py                       # 1 GPU, defaults finish in a few minutes
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+HIP events on the launch stream) and `cpu_baseline` (oracle timed on this host's cores, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+PEAK_MFMA_TFLOPS = 2500.0   # dense bf16 / f16
+
+PROF_NAMES = {1: "gemm_kernel (encoder / cross-KV MFMA GEMM)", 2: "encoder_attention_kernel", 3: "cross_attn_kernel (decoder)",
+              4: "dec_gemm_kernel (decoder weight streaming)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="large-v3")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--tokens", type=int, default=100)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--profile-class", type=int, default=0, help="0 = pick the class with the largest total time")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tokens", type=int, default=0, help="decode tokens in the CPU sample (0 = same as --tokens)")
+    args = ap.parse_args()
+
+    import torch
+    from openhush_amd import engine as E, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    hp = synth.PRESETS[args.model]
+    dtype = E.OHW_DTYPE_BF16 if args.dtype == "bf16" else E.OHW_DTYPE_F16
+    B = args.batch
+    ctx = E.Context.synthetic(hp.as_list(), 1234, local_rank, dtype)
+    st = E.State(ctx, B)
+    stream = torch.cuda.current_stream()
+    st.set_stream(stream.cuda_stream)
+
+    # synthetic 16 kHz audio: window ids are global so that every rank transcribes different audio
+    pcm_host = np.stack([synth.synth_audio(rank * B + b) for b in range(B)])
+    pcm = torch.from_numpy(pcm_host).cuda()
+    n_samples = [synth.CHUNK_SAMPLES] * B
+    p = ctx.default_params()
+    p.force_len = args.tokens
+
+    tokens_dev = torch.zeros(B, args.tokens, dtype=torch.int32, device="cuda")
+    gathered = [torch.zeros_like(tokens_dev) for _ in range(world)] if rank == 0 and world > 1 else None
+
+    def step():
+        st.mel_device(pcm.data_ptr(), pcm.shape[1], n_samples, E.OHW_MEL_ZERO_TAIL)
+        st.encode(B)
+        toks, _ = st.greedy(B, p)
+        if world > 1:
+            tokens_dev.copy_(torch.tensor(toks, dtype=torch.int32), non_blocking=False)
+            dist.gather(tokens_dev, gathered, dst=0)
+        return toks
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        toks = step()
+    # pick the dominant kernel class from one untimed profiling pass per class (HIP events on the stream)
+    prof_class = args.profile_class
+    class_totals = {}
+    if prof_class == 0:
+        for cls in (1, 2, 3, 4):
+            st.profile_begin(cls)
+            step()
+            n, ms, w = st.profile_end()
+            class_totals[cls] = ms
+        prof_class = max(class_totals, key=class_totals.get)
+
+    fence()
+    st.profile_begin(prof_class)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        toks = step()
+    fence()
+    dt = time.perf_counter() - t0
+    launches, k_ms, work = st.profile_end()
+    tm = st.timings()
+
+    dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+    dt_max = float(dt_t.item())
+    audio_s = 30.0 * B * world * args.steps
+    value = audio_s / dt_max
+
+    assert all(len(t) == args.tokens for t in toks), "every window must decode exactly --tokens tokens"
+
+    if rank == 0:
+        if prof_class in (1, 2):
+            achieved = work / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+            roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": None}
+        else:
+            achieved = work / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
+        roof.update({"kernel": PROF_NAMES[prof_class], "launches": launches, "avg_launch_us": round(1e3 * k_ms / max(1, launches), 2),
+                     "kernel_ms_per_step": round(k_ms / args.steps, 3),
+                     "class_ms_per_step": {PROF_NAMES[k]: round(v, 3) for k, v in class_totals.items()}})
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(hp, pcm_host[0], args.cpu_tokens or args.tokens)
+        line = {
+            "metric": "audio-sec/sec (xRT) large-v3 greedy, 30s chunks", "value": round(value, 1), "unit": "audio-sec/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.model} dims, batch={B} x 30 s windows per GPU, greedy, {args.tokens} tokens/window (EOT suppressed), "
+                                   f"procedural weights seed 1234, PCM resident in HBM", "model_dims": hp.as_list(),
+                       "stage_ms_last_step": {"mel": round(tm.mel_ms, 2), "encode": round(tm.encode_ms, 2), "decode": round(tm.decode_ms, 2)},
+                       "decode_steps": tm.decode_steps},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(hp, pcm, n_tokens):
+    """The oracle (kind "port") on this host's cores: ONE 30 s window of the same workload."""
+    from oracle import oracle
+    cores = len(os.sched_getaffinity(0))
+    oracle.set_num_threads(cores)
+    m = oracle.Model.synth(hp.as_list(), 1234)
+    p = m.default_params()
+    p.force_len = n_tokens
+    t0 = time.perf_counter()
+    toks, (t_mel, t_enc, t_dec) = m.transcribe_chunk(pcm, p, 1)
+    dt = time.perf_counter() - t0
+    assert len(toks) == n_tokens
+    m.close()
+    return {"value": round(30.0 / dt, 3), "unit": "audio-sec/sec", "cores": cores, "kind": "port",
+            "sample": f"1 window (30 s) of the same workload, {n_tokens} decode tokens, fp32 C/OpenMP oracle: mel {t_mel:.2f} s, "
+                      f"encoder+crossKV {t_enc:.2f} s, decode {t_dec:.2f} s"}
+
+
+if __name__ == "__main__":
+    main()

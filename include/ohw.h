@@ -137,6 +137,14 @@ int ohw_greedy(ohw_state* st, const ohw_sample_params* p, int batch, int32_t* to
 typedef struct { float mel_ms, encode_ms, decode_ms, total_ms; int32_t decode_steps; } ohw_timings;
 int ohw_state_timings(ohw_state* st, ohw_timings* t);
 
+/* per-kernel-class timing with HIP events on the state's stream (bench.py's roofline leg).        */
+/* Classes: 1 encoder/cross-KV MFMA GEMM, 2 encoder attention, 3 decoder cross-attention,          */
+/* 4 decoder weight-streaming GEMM.  work = algorithmic flops (1, 2) or bytes (3, 4) summed over    */
+/* the launches between begin and end.                                                             */
+enum { OHW_PROF_NONE = 0, OHW_PROF_ENC_GEMM = 1, OHW_PROF_ENC_ATTN = 2, OHW_PROF_DEC_XATTN = 3, OHW_PROF_DEC_GEMM = 4 };
+int ohw_state_profile_begin(ohw_state* st, int kernel_class);
+int ohw_state_profile_end(ohw_state* st, int64_t* launches, double* total_ms, double* work);
+
 /* ---- WhisperEngine mirror (reference src/engine/whisper.rs:110-387): the host driver written   */
 /*      in C++ because no Rust toolchain exists in the build image --------------------------------- */
 typedef struct ohw_engine ohw_engine;
@@ -167,8 +175,9 @@ int ohw_abi_version(void);
 /* copy an internal activation to the host as f32: what = "mel" [B][n_mels][3000], "conv1"        */
 /* [B][3000][d], "stem" / "block0" / "enc" [B][1500][d], "xk<l>" / "xv<l>" [B][1500][d]            */
 int ohw_state_fetch(ohw_state* st, const char* what, int batch, float* out, int64_t out_elems);
-/* copy a weight tensor back as f32 in the model file's layout (checks synthetic == file)          */
-int ohw_ctx_fetch_tensor(const ohw_ctx* ctx, const char* name, float* out, int64_t out_elems);
+/* 64-bit digest of the index-th resident weight buffer (engine layout); returns OHW_E_INVALID_ARG  */
+/* past the last buffer.  Lets tests prove "synthetic ctx == ctx loaded from the synthetic file".  */
+int ohw_ctx_weight_digest(const ohw_ctx* ctx, int index, char* name_out /* >= 64 bytes */, uint64_t* digest);
 /* kernel-level entry points on raw device pointers (tests against a torch fp32 reference)         */
 int ohw_dbg_gemm(int dtype, const void* A, const void* W, const float* bias, void* out, int64_t M, int64_t N,
                  int64_t K, int epilogue, void* stream);

@@ -64,6 +64,11 @@ struct ohw_state {
   DevBuf step_tok, n_past, tokens, n_cur, next_tok, done, n_done, sum_lp;
   int m_max = 0;
   int64_t logits_ld = 0;
+  // per-kernel-class profiling (bench): event pairs around every launch of one class
+  int prof_class = 0;
+  std::vector<hipEvent_t> prof_ev;
+  size_t prof_used = 0;
+  double prof_work = 0.0;
   // timing
   hipEvent_t ev[6]{};
   ohw_timings last{};
@@ -71,6 +76,26 @@ struct ohw_state {
 };
 
 namespace {
+
+struct ProfScope {
+  ohw_state* st;
+  bool on;
+  ProfScope(ohw_state* s, int cls, double work) : st(s), on(s->prof_class == cls) {
+    if (!on) return;
+    if (st->prof_used + 2 > st->prof_ev.size()) {
+      const size_t old = st->prof_ev.size();
+      st->prof_ev.resize(old + 1024);
+      for (size_t i = old; i < st->prof_ev.size(); ++i) HIP_CHECK(hipEventCreate(&st->prof_ev[i]));
+    }
+    HIP_CHECK(hipEventRecord(st->prof_ev[st->prof_used], st->stream));
+    st->prof_work += work;
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(st->prof_ev[st->prof_used + 1], st->stream);
+    st->prof_used += 2;
+  }
+};
 
 struct Dispatch {
   template <typename F> static void run(int dtype, F&& f) {
@@ -148,7 +173,7 @@ void run_encode(ohw_state* st, int B) {
   g.M = (int64_t)B * CHUNK_FRAMES; g.N = d; g.K = 3 * MEL_CPAD;
   g.lda = MEL_CPAD; g.a_batch_stride = (int64_t)MEL_ROWS * MEL_CPAD; g.rows_per_batch = CHUNK_FRAMES;
   g.ldc = d; g.c_batch_stride = (int64_t)MEL_ROWS * d;
-  launch_gemm<T>(g, EPI_BIAS_GELU_T, s);
+  { ProfScope ps(st, OHW_PROF_ENC_GEMM, 2.0 * g.M * g.N * g.K); launch_gemm<T>(g, EPI_BIAS_GELU_T, s); }
   // conv2 (k=3, stride 2, pad 1): row t reads image rows 2t .. 2t+2 of conv1's padded output
   g = GemmParams{};
   g.A = st->c1.p; g.W = c->conv2_w.p; g.bias = c->conv2_b.as<float>(); g.pos = c->enc_pos.as<float>();
@@ -156,20 +181,24 @@ void run_encode(ohw_state* st, int B) {
   g.M = M; g.N = d; g.K = 3 * d;
   g.lda = 2 * d; g.a_batch_stride = (int64_t)MEL_ROWS * d; g.rows_per_batch = Tn;
   g.ldc = d; g.c_batch_stride = Tn * d;
-  launch_gemm<T>(g, EPI_GELU_POS_F32, s);
+  { ProfScope ps(st, OHW_PROF_ENC_GEMM, 2.0 * g.M * g.N * g.K); launch_gemm<T>(g, EPI_GELU_POS_F32, s); }
   if (st->taps) HIP_CHECK(hipMemcpyAsync(st->tap_stem.p, st->h.p, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
 
   auto dense = [&](const void* A, int64_t K, const DevBuf& W, const DevBuf& bias, void* out, int64_t N, int epi) {
     GemmParams q{};
     q.A = A; q.W = W.p; q.bias = bias.as<float>(); q.out = out;
     q.M = M; q.N = N; q.K = K; q.lda = K; q.a_batch_stride = 0; q.rows_per_batch = M; q.ldc = N; q.c_batch_stride = 0;
+    ProfScope ps(st, OHW_PROF_ENC_GEMM, 2.0 * q.M * q.N * q.K);
     launch_gemm<T>(q, epi, s);
   };
   for (int l = 0; l < hp.n_audio_layer; ++l) {
     const EncLayerW& w = c->enc[l];
     launch_layernorm<T>(st->h.as<float>(), w.ln1.g.as<float>(), w.ln1.b.as<float>(), st->y.p, M, (int)d, s);
     dense(st->y.p, d, w.wqkv, w.bqkv, st->qkv.p, 3 * d, EPI_BIAS_T);
-    launch_encoder_attention<T>(st->qkv.p, st->att.p, B, (int)Tn, hp.n_audio_head, s);
+    {
+      ProfScope ps(st, OHW_PROF_ENC_ATTN, 4.0 * B * hp.n_audio_head * (double)Tn * (double)Tn * 64.0);
+      launch_encoder_attention<T>(st->qkv.p, st->att.p, B, (int)Tn, hp.n_audio_head, s);
+    }
     dense(st->att.p, d, w.wo, w.bo, st->h.p, d, EPI_BIAS_RESID_F32);
     launch_layernorm<T>(st->h.as<float>(), w.ln2.g.as<float>(), w.ln2.b.as<float>(), st->y.p, M, (int)d, s);
     dense(st->y.p, d, w.w1, w.b1, st->ffn.p, 4 * d, EPI_BIAS_GELU_T);
@@ -183,7 +212,7 @@ void run_encode(ohw_state* st, int B) {
   g.M = M; g.N = (int64_t)2 * hp.n_text_layer * hp.n_text_state; g.K = d;
   g.lda = d; g.a_batch_stride = Tn * d; g.rows_per_batch = Tn; g.ldc = 0; g.c_batch_stride = 0;
   g.d_model = hp.n_text_state; g.n_head = hp.n_text_head; g.t_len = (int)Tn; g.batch = B;
-  launch_gemm<T>(g, EPI_CROSSKV_T, s);
+  { ProfScope ps(st, OHW_PROF_ENC_GEMM, 2.0 * g.M * g.N * g.K); launch_gemm<T>(g, EPI_CROSSKV_T, s); }
 }
 
 // one decoder pass over M = B * n_new rows; tokens in st->step_tok, positions from st->n_past
@@ -204,6 +233,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
     p.x = x; p.w = w.p; p.bias = bias.p ? bias.as<float>() : nullptr; p.out = out;
     p.M = M; p.N = N; p.K = K; p.n_new = n_new; p.ld_out = ld; p.n_past = n_past;
     p.d_model = d; p.n_head = H; p.n_ctx = C;
+    ProfScope ps(st, OHW_PROF_DEC_GEMM, 2.0 * ((double)((N + 15) / 16 * 16) * K) * ((M + 31) / 32));
     launch_dec_gemm<T>(p, epi, s);
   };
   for (int l = 0; l < L; ++l) {
@@ -216,12 +246,14 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
       p.x = st->dy.p; p.w = w.wqkv.p; p.bias = w.bqkv.as<float>(); p.out = st->dq.p;
       p.M = M; p.N = 3 * d; p.K = d; p.n_new = n_new; p.ld_out = d;
       p.k_cache = kc; p.v_cache = vc; p.n_past = n_past; p.d_model = d; p.n_head = H; p.n_ctx = C;
+      ProfScope ps(st, OHW_PROF_DEC_GEMM, 2.0 * (3.0 * d * d) * ((M + 31) / 32));
       launch_dec_gemm<T>(p, DEPI_QKV, s);
     }
     launch_self_attn<T>(st->dq.p, kc, vc, n_past, st->da.p, M, n_new, H, C, s);
     gemm(st->da.p, w.wo, w.bo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
     launch_layernorm<T>(st->dx.as<float>(), w.lnx.g.as<float>(), w.lnx.b.as<float>(), st->dy.p, M, d, s);
     gemm(st->dy.p, w.wxq, w.bxq, st->dq.p, d, d, DEPI_BIAS_T, d);
+    ProfScope psx(st, OHW_PROF_DEC_XATTN, 2.0 * 2.0 * (double)M * H * Tn * 64.0);
     launch_cross_attn<T>(st->dq.p, (const T*)st->xkv.p + (int64_t)(2 * l) * xkv_slab, (const T*)st->xkv.p + (int64_t)(2 * l + 1) * xkv_slab,
                          st->da.p, M, n_new, H, Tn, s);
     gemm(st->da.p, w.wxo, w.bxo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
@@ -328,6 +360,7 @@ void ohw_state_free(ohw_state* st) {
   (void)hipSetDevice(st->ctx->device);
   (void)hipDeviceSynchronize();
   for (auto& e : st->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : st->prof_ev) if (e) (void)hipEventDestroy(e);
   if (st->own_stream) (void)hipStreamDestroy(st->own_stream);
   delete st;
 }
@@ -510,6 +543,36 @@ int ohw_state_timings(ohw_state* st, ohw_timings* t) {
   });
 }
 
+int ohw_state_profile_begin(ohw_state* st, int kernel_class) {
+  return guard([&] {
+    if (!st) throw Error(OHW_E_INVALID_ARG, "state is null");
+    if (kernel_class < 0 || kernel_class > 4) throw Error(OHW_E_INVALID_ARG, "unknown kernel class");
+    HIP_CHECK(hipSetDevice(st->ctx->device));
+    st->prof_class = kernel_class;
+    st->prof_used = 0;
+    st->prof_work = 0.0;
+  });
+}
+
+int ohw_state_profile_end(ohw_state* st, int64_t* launches, double* total_ms, double* work) {
+  return guard([&] {
+    if (!st) throw Error(OHW_E_INVALID_ARG, "state is null");
+    HIP_CHECK(hipSetDevice(st->ctx->device));
+    HIP_CHECK(hipStreamSynchronize(st->stream));
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < st->prof_used; i += 2) {
+      float t = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&t, st->prof_ev[i], st->prof_ev[i + 1]));
+      ms += t;
+    }
+    if (launches) *launches = (int64_t)(st->prof_used / 2);
+    if (total_ms) *total_ms = ms;
+    if (work) *work = st->prof_work;
+    st->prof_class = 0;
+    st->prof_used = 0;
+  });
+}
+
 int ohw_state_fetch(ohw_state* st, const char* what, int batch, float* out, int64_t out_elems) {
   return guard([&] {
     if (!st || !what || !out) throw Error(OHW_E_INVALID_ARG, "null argument");
@@ -585,6 +648,43 @@ int ohw_state_fetch(ohw_state* st, const char* what, int batch, float* out, int6
       return;
     }
     throw Error(OHW_E_INVALID_ARG, std::string("fetch: unknown activation '") + what + "'");
+  });
+}
+
+int ohw_ctx_weight_digest(const ohw_ctx* ctx, int index, char* name_out, uint64_t* digest) {
+  return guard([&] {
+    if (!ctx || !name_out || !digest || index < 0) throw Error(OHW_E_INVALID_ARG, "bad argument");
+    std::vector<std::pair<std::string, const DevBuf*>> bufs;
+    auto add = [&](const std::string& n, const DevBuf& b) { bufs.emplace_back(n, &b); };
+    add("mel_filters", ctx->mel_filters); add("conv1_w", ctx->conv1_w); add("conv1_b", ctx->conv1_b);
+    add("conv2_w", ctx->conv2_w); add("conv2_b", ctx->conv2_b); add("enc_pos", ctx->enc_pos);
+    for (size_t i = 0; i < ctx->enc.size(); ++i) {
+      const EncLayerW& l = ctx->enc[i];
+      const std::string p = "enc" + std::to_string(i) + ".";
+      add(p + "ln1.g", l.ln1.g); add(p + "ln1.b", l.ln1.b); add(p + "wqkv", l.wqkv); add(p + "bqkv", l.bqkv);
+      add(p + "wo", l.wo); add(p + "bo", l.bo); add(p + "ln2.g", l.ln2.g); add(p + "ln2.b", l.ln2.b);
+      add(p + "w1", l.w1); add(p + "b1", l.b1); add(p + "w2", l.w2); add(p + "b2", l.b2);
+    }
+    add("ln_post.g", ctx->ln_post.g); add("ln_post.b", ctx->ln_post.b); add("xkv_w", ctx->xkv_w); add("xkv_b", ctx->xkv_b);
+    add("dec_pos", ctx->dec_pos); add("emb", ctx->emb);
+    for (size_t i = 0; i < ctx->dec.size(); ++i) {
+      const DecLayerW& l = ctx->dec[i];
+      const std::string p = "dec" + std::to_string(i) + ".";
+      add(p + "ln1.g", l.ln1.g); add(p + "ln1.b", l.ln1.b); add(p + "wqkv", l.wqkv); add(p + "bqkv", l.bqkv);
+      add(p + "wo", l.wo); add(p + "bo", l.bo); add(p + "lnx.g", l.lnx.g); add(p + "lnx.b", l.lnx.b);
+      add(p + "wxq", l.wxq); add(p + "bxq", l.bxq); add(p + "wxo", l.wxo); add(p + "bxo", l.bxo);
+      add(p + "ln2.g", l.ln2.g); add(p + "ln2.b", l.ln2.b); add(p + "w1", l.w1); add(p + "b1", l.b1); add(p + "w2", l.w2); add(p + "b2", l.b2);
+    }
+    add("dec_ln.g", ctx->dec_ln.g); add("dec_ln.b", ctx->dec_ln.b);
+    if ((size_t)index >= bufs.size()) throw Error(OHW_E_INVALID_ARG, "index past the last weight buffer");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const DevBuf& b = *bufs[(size_t)index].second;
+    std::vector<unsigned char> host(b.bytes);
+    HIP_CHECK(hipMemcpy(host.data(), b.p, b.bytes, hipMemcpyDeviceToHost));
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (unsigned char c : host) { h ^= c; h *= 0x100000001b3ull; }
+    *digest = h;
+    std::snprintf(name_out, 64, "%s", bufs[(size_t)index].first.c_str());
   });
 }
 

@@ -65,7 +65,7 @@ EXPORTS = [
     "ohw_default_sample_params", "ohw_sample_greedy_host", "ohw_greedy", "ohw_state_timings", "ohw_engine_new",
     "ohw_engine_transcribe", "ohw_engine_last_tokens", "ohw_engine_benchmark", "ohw_engine_free", "ohw_engine_state",
     "ohw_engine_ctx", "ohw_lang_id_to_code", "ohw_lang_code_to_id", "ohw_last_error", "ohw_abi_version", "ohw_state_fetch",
-    "ohw_dbg_gemm", "ohw_dbg_attention",
+    "ohw_dbg_gemm", "ohw_dbg_attention", "ohw_state_profile_begin", "ohw_state_profile_end", "ohw_ctx_weight_digest",
 ]
 
 
@@ -141,6 +141,9 @@ def lib():
         L.ohw_engine_ctx.argtypes = [vp]
         L.ohw_engine_ctx.restype = vp
         L.ohw_state_fetch.argtypes = [vp, C.c_char_p, C.c_int, fp, C.c_int64]
+        L.ohw_state_profile_begin.argtypes = [vp, C.c_int]
+        L.ohw_state_profile_end.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.ohw_ctx_weight_digest.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(C.c_uint64)]
         L.ohw_dbg_gemm.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, vp]
         L.ohw_dbg_attention.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]
         _lib = L
@@ -222,6 +225,16 @@ class Context:
         p = SampleParams()
         lib().ohw_default_sample_params(self.h, C.byref(p))
         return p
+
+    def weight_digests(self) -> dict:
+        """name -> 64-bit digest of every resident weight buffer"""
+        out, i = {}, 0
+        name = C.create_string_buffer(64)
+        d = C.c_uint64(0)
+        while lib().ohw_ctx_weight_digest(self.h, i, name, C.byref(d)) == 0:
+            out[name.value.decode()] = int(d.value)
+            i += 1
+        return out
 
     def token_text(self, i: int) -> bytes:
         s = C.c_char_p()
@@ -340,6 +353,15 @@ class State:
             logits = self.decode(np.asarray(feed, np.int32).reshape(batch, 1), n_past)
             n_past = [n + (0 if done[b] else 1) for b, n in enumerate(n_past)]
         return out
+
+    def profile_begin(self, kernel_class: int):
+        _check(lib().ohw_state_profile_begin(self.h, kernel_class))
+
+    def profile_end(self):
+        """(launches, total_ms, work) for the class given to profile_begin"""
+        n, ms, w = C.c_int64(0), C.c_double(0), C.c_double(0)
+        _check(lib().ohw_state_profile_end(self.h, C.byref(n), C.byref(ms), C.byref(w)))
+        return int(n.value), float(ms.value), float(w.value)
 
     def timings(self) -> Timings:
         t = Timings()
