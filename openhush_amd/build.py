@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libohw.so")
 BUILD = os.path.join(CSRC, "_build")
 SOURCES = ["gemm.hip", "attention.hip", "weights.hip", "mel.hip", "misc.hip", "decode.hip", "model.hip", "engine.hip", "host_engine.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=fast",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=fast-honor-pragmas",
          "-fno-gpu-rdc", "-x", "hip"]
 
 

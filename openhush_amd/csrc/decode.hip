@@ -7,6 +7,8 @@
 //     16 output rows as consecutive 1-KiB blocks straight into VGPRs (no LDS round trip: the weights
 //     are used once; cdna_hip_programming.md "GEMV / M <= 16 decode weights"),
 //   * cross K/V are head-major [B][H][1500][64]: one (window, head) = 192 KiB contiguous per tensor.
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace ohw {
@@ -34,68 +36,178 @@ void launch_embed(const void* emb, const float* pos, const int32_t* tok, const i
 }
 
 // ------------------------------------------------------------------------------------------------
-// skinny GEMM  y[M][N] = x[M][K] * W[N][K]^T  for M <= 32 per pass, W in fragment tiles.
-// grid = (Npad/16, ceil(M/32)); 4 waves split K (interleaved 1-KiB blocks), reduce through LDS in a
-// fixed order (bitwise reproducible, no atomics).
+// skinny GEMM  y[M][N] = f(x)[M][K] * W[N][K]^T  for 32 rows per pass, W in fragment tiles.
+// grid = (Npad/16, ceil(M/32)); 8 waves split K (interleaved 1-KiB blocks, every block of a wave's
+// share in flight at once: the kernel is latency-bound, not issue-bound), fixed-order LDS reduction
+// (bitwise reproducible, no atomics).
+// LN = true fuses the pre-LayerNorm of the fp32 residual stream into the prologue: the workgroup
+// normalises its 32 rows into LDS (16-bit, rows padded by 16 B against bank conflicts) and the MFMA
+// B operand is read from there.  Every workgroup redoes the 32-row LN (160 KB of L2 reads) - cheaper
+// than one more dependent launch in a chain of 5 us kernels.
 // ------------------------------------------------------------------------------------------------
-constexpr int DG_THREADS = 256;
+constexpr int DG_THREADS = 512;
+constexpr int DG_WAVES = DG_THREADS / 64;
+constexpr int DG_LN_MAXK = 1280;  // fused LayerNorm: 16 threads per row, 20 float4 each
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(DG_THREADS) void dec_gemm_kernel(DecGemmParams p) {
+template <typename T, int EPI, bool LN, int NT>
+__global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p) {
   using Ops = TypeOps<T>;
   using vec8 = typename Ops::vec8;
-  __shared__ f32x4 part[4][2][64];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dg_smem[];
+  f32x4* part = (f32x4*)dg_smem;                                      // [8 waves][NT][2][64]
+  unsigned char* ylds = dg_smem + DG_WAVES * NT * 2 * 64 * 16;        // LN: [32][K*2 + 16] bytes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nt = blockIdx.x;
+  const int nt0 = blockIdx.x * NT;
   const int m0 = blockIdx.y * 32;
   const int kblocks = p.K / 32;
-  const vec8* __restrict__ wt = (const vec8*)p.w + (int64_t)nt * kblocks * 64 + lane;
+  const int ystride = p.K * 2 + 16;
+  const int n_tiles = (p.N + 15) / 16;
+
+  // epilogue coordinates are known up front: one output per thread and n-tile
+  const int e_mt = tid >> 8, e_ll = (tid >> 2) & 63, e_reg = tid & 3;
+  const int e_m = m0 + e_mt * 16 + (e_ll & 15);
+  float resid_old[NT];
+  if constexpr (EPI == DEPI_BIAS_RESID) {
+    // issue the read of the residual now: its latency hides under the weight stream
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = (nt0 + t) * 16 + 4 * (e_ll >> 4) + e_reg;
+      resid_old[t] = (e_m < p.M && n < p.N) ? ((const float*)p.out)[(int64_t)e_m * p.ld_out + n] : 0.f;
+    }
+  }
+
+  if constexpr (LN) {
+    // all 512 threads: row = tid / 16, 16 threads per row, every load of the 32 x K tile in flight at once
+    const float* __restrict__ xf = (const float*)p.x;
+    const int row = tid >> 4, sub = tid & 15;
+    int m = m0 + row;
+    if (m > p.M - 1) m = p.M - 1;
+    const float* xr = xf + (int64_t)m * p.K;
+    constexpr int NV = DG_LN_MAXK / 64;
+    // every load is unconditional (clamped column, masked value): a per-element "load or zero" branch
+    // makes hipcc wait vmcnt(0) per element and serialises 20 L2 round trips
+    f32x4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 16 + sub) * 4;
+      const int cc = c < p.K ? c : 0;
+      v[i] = *(const f32x4*)(xr + cc);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 16 + sub) * 4;
+      const float ok = c < p.K ? 1.f : 0.f;
+      sum += ok * ((v[i].x + v[i].y) + (v[i].z + v[i].w));
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum / (float)p.K;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 16 + sub) * 4;
+      const float ok = c < p.K ? 1.f : 0.f;
+      const float a = v[i].x - mean, b2 = v[i].y - mean, c2 = v[i].z - mean, d2 = v[i].w - mean;
+      var += ok * ((a * a + b2 * b2) + (c2 * c2 + d2 * d2));
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    const float rstd = rsqrtf(var / (float)p.K + 1e-5f);
+    // gamma / beta in groups of 5 float4 (L2 hits; all 5 of a group in flight)
+#pragma unroll
+    for (int i0 = 0; i0 < NV; i0 += 5) {
+      f32x4 g[5], bb[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int c = ((i0 + j) * 16 + sub) * 4;
+        const int cc = c < p.K ? c : 0;
+        g[j] = *(const f32x4*)(p.ln_g + cc);
+        bb[j] = *(const f32x4*)(p.ln_b + cc);
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int i = i0 + j;
+        const int c = (i * 16 + sub) * 4;
+        u32x2 w2;
+        w2.x = pack2<T>((v[i].x - mean) * rstd * g[j].x + bb[j].x, (v[i].y - mean) * rstd * g[j].y + bb[j].y);
+        w2.y = pack2<T>((v[i].z - mean) * rstd * g[j].z + bb[j].z, (v[i].w - mean) * rstd * g[j].w + bb[j].w);
+        if (c < p.K) *(u32x2*)(ylds + row * ystride + c * 2) = w2;
+      }
+    }
+    __syncthreads();
+  }
+
   const T* __restrict__ x = (const T*)p.x;
   int r0 = m0 + (lane & 15), r1 = m0 + 16 + (lane & 15);
   if (r0 > p.M - 1) r0 = p.M - 1;
   if (r1 > p.M - 1) r1 = p.M - 1;
-  const T* x0 = x + (int64_t)r0 * p.K + (lane >> 4) * 8;
-  const T* x1 = x + (int64_t)r1 * p.K + (lane >> 4) * 8;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const T* x0 = LN ? nullptr : x + (int64_t)r0 * p.K + (lane >> 4) * 8;
+  const T* x1 = LN ? nullptr : x + (int64_t)r1 * p.K + (lane >> 4) * 8;
+  const unsigned char* y0 = ylds + (lane & 15) * ystride + (lane >> 4) * 16;
+  const unsigned char* y1 = y0 + 16 * ystride;
+  const vec8* wt[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    int nt = nt0 + t;
+    if (nt > n_tiles - 1) nt = n_tiles - 1;   // ragged last workgroup: recompute the last tile, never stored
+    wt[t] = (const vec8*)p.w + (int64_t)nt * kblocks * 64 + lane;
+  }
+  f32x4 acc[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  auto run = [&](auto ucount, int kb) {
+    constexpr int U = decltype(ucount)::value;
+    vec8 w[NT][U], a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) w[t][u] = __builtin_nontemporal_load(&wt[t][(int64_t)(kb + DG_WAVES * u) * 64]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kk = kb + DG_WAVES * u;
+      if constexpr (LN) {
+        a[u] = *(const vec8*)(y0 + kk * 64);
+        b[u] = *(const vec8*)(y1 + kk * 64);
+      } else {
+        a[u] = *(const vec8*)(x0 + kk * 32);
+        b[u] = *(const vec8*)(x1 + kk * 32);
+      }
+    }
+    // keep every load above issued before the first MFMA (the scheduler otherwise sinks loads next to
+    // their use to save registers and the wave pays one HBM round trip per k-block)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t][0] = Ops::mfma16(w[t][u], a[u], acc[t][0]);
+        acc[t][1] = Ops::mfma16(w[t][u], b[u], acc[t][1]);
+      }
+  };
   int kb = wave;
-  // main loop, 4 k-blocks in flight per wave
-  for (; kb + 12 < kblocks; kb += 16) {
-    vec8 w[4], a[4], b[4];
+  for (; kb + DG_WAVES * 9 < kblocks; kb += DG_WAVES * 10) run(std::integral_constant<int, 10>{}, kb);
+  for (; kb + DG_WAVES * 4 < kblocks; kb += DG_WAVES * 5) run(std::integral_constant<int, 5>{}, kb);
+  for (; kb < kblocks; kb += DG_WAVES) run(std::integral_constant<int, 1>{}, kb);
+
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      w[u] = wt[(int64_t)(kb + 4 * u) * 64];
-      a[u] = *(const vec8*)(x0 + (kb + 4 * u) * 32);
-      b[u] = *(const vec8*)(x1 + (kb + 4 * u) * 32);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc0 = Ops::mfma16(w[u], a[u], acc0);
-      acc1 = Ops::mfma16(w[u], b[u], acc1);
-    }
+  for (int t = 0; t < NT; ++t) {
+    part[((wave * NT + t) * 2 + 0) * 64 + lane] = acc[t][0];
+    part[((wave * NT + t) * 2 + 1) * 64 + lane] = acc[t][1];
   }
-  for (; kb < kblocks; kb += 4) {
-    vec8 w = wt[(int64_t)kb * 64];
-    vec8 a = *(const vec8*)(x0 + kb * 32);
-    vec8 b = *(const vec8*)(x1 + kb * 32);
-    acc0 = Ops::mfma16(w, a, acc0);
-    acc1 = Ops::mfma16(w, b, acc1);
-  }
-  part[wave][0][lane] = acc0;
-  part[wave][1][lane] = acc1;
   __syncthreads();
-  // 2 m-tiles x 64 lanes x 4 regs = 512 outputs; thread -> (mt, lane', reg pair)
+  // per n-tile: 2 m-tiles x 64 lanes x 4 regs = 512 outputs, one per thread
   // D layout: n = 4*(lane'>>4) + reg, m = mt*16 + (lane' & 15)
+  const float* pp = (const float*)part;
 #pragma unroll
-  for (int rep = 0; rep < 2; ++rep) {
-    const int o = tid + rep * DG_THREADS;      // 0..511
-    const int mt = o >> 8, ll = (o >> 2) & 63, reg = o & 3;
-    const float* pp = (const float*)&part[0][0][0];
+  for (int t = 0; t < NT; ++t) {
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) v += pp[((w * 2 + mt) * 64 + ll) * 4 + reg];
-    const int n = nt * 16 + 4 * (ll >> 4) + reg;
-    const int m = m0 + mt * 16 + (ll & 15);
-    if (m >= p.M || n >= p.N) continue;
+    for (int w = 0; w < DG_WAVES; ++w) v += pp[(((w * NT + t) * 2 + e_mt) * 64 + e_ll) * 4 + e_reg];
+    const int n = (nt0 + t) * 16 + 4 * (e_ll >> 4) + e_reg;
+    const int m = e_m;
+    if (m >= p.M || n >= p.N || nt0 + t >= n_tiles) continue;
     if (p.bias) v += p.bias[n];
     if constexpr (EPI == DEPI_QKV) {
       const int d = p.d_model;
@@ -114,23 +226,45 @@ __global__ __launch_bounds__(DG_THREADS) void dec_gemm_kernel(DecGemmParams p) {
     } else if constexpr (EPI == DEPI_BIAS_GELU_T) {
       ((T*)p.out)[(int64_t)m * p.ld_out + n] = (T)gelu_erf(v);
     } else if constexpr (EPI == DEPI_BIAS_RESID) {
-      ((float*)p.out)[(int64_t)m * p.ld_out + n] += v;
+      ((float*)p.out)[(int64_t)m * p.ld_out + n] = resid_old[t] + v;
     } else if constexpr (EPI == DEPI_LOGITS) {
       if (m % p.n_new == p.n_new - 1) ((float*)p.out)[(int64_t)(m / p.n_new) * p.ld_out + n] = v;
     }
   }
 }
 
+template <typename T, int EPI, bool LN, int NT>
+static void dec_gemm_launch(const DecGemmParams& p, hipStream_t s) {
+  const int n_tiles = (p.N + 15) / 16;
+  dim3 grid((n_tiles + NT - 1) / NT, (p.M + 31) / 32);
+  const size_t smem = (size_t)DG_WAVES * NT * 2 * 64 * 16 + (LN ? (size_t)32 * (p.K * 2 + 16) : 0);
+  static bool attr_set = false;
+  if (LN && !attr_set) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)dec_gemm_kernel<T, EPI, LN, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, LN, NT>), grid, dim3(DG_THREADS), smem, s, p);
+}
+
+template <typename T, int EPI, bool LN>
+static void dec_gemm_pick(const DecGemmParams& p, hipStream_t s) {
+  // with the LayerNorm image in LDS one workgroup fills a CU: keep the grid within one wave of 256 CUs
+  const int n_tiles = (p.N + 15) / 16;
+  if (LN && n_tiles > 256) dec_gemm_launch<T, EPI, LN, 2>(p, s);
+  else dec_gemm_launch<T, EPI, LN, 1>(p, s);
+}
+
 template <typename T>
 void launch_dec_gemm(const DecGemmParams& p, int epilogue, hipStream_t s) {
   if (p.K % 32 != 0) throw Error(OHW_E_INVALID_ARG, "dec_gemm: K must be a multiple of 32");
-  dim3 grid((p.N + 15) / 16, (p.M + 31) / 32);
+  const bool ln = p.ln_g != nullptr;
+  if (ln && (p.K % 64 != 0 || p.K > DG_LN_MAXK || !p.ln_b)) throw Error(OHW_E_INVALID_ARG, "dec_gemm: fused LayerNorm needs K <= 1280, K % 64 == 0");
   switch (epilogue) {
-    case DEPI_QKV: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_QKV>), grid, dim3(DG_THREADS), 0, s, p); break;
-    case DEPI_BIAS_T: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_BIAS_T>), grid, dim3(DG_THREADS), 0, s, p); break;
-    case DEPI_BIAS_GELU_T: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_BIAS_GELU_T>), grid, dim3(DG_THREADS), 0, s, p); break;
-    case DEPI_BIAS_RESID: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_BIAS_RESID>), grid, dim3(DG_THREADS), 0, s, p); break;
-    case DEPI_LOGITS: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_LOGITS>), grid, dim3(DG_THREADS), 0, s, p); break;
+    case DEPI_QKV: if (ln) dec_gemm_pick<T, DEPI_QKV, true>(p, s); else dec_gemm_pick<T, DEPI_QKV, false>(p, s); break;
+    case DEPI_BIAS_T: if (ln) dec_gemm_pick<T, DEPI_BIAS_T, true>(p, s); else dec_gemm_pick<T, DEPI_BIAS_T, false>(p, s); break;
+    case DEPI_BIAS_GELU_T: if (ln) dec_gemm_pick<T, DEPI_BIAS_GELU_T, true>(p, s); else dec_gemm_pick<T, DEPI_BIAS_GELU_T, false>(p, s); break;
+    case DEPI_BIAS_RESID: if (ln) throw Error(OHW_E_INVALID_ARG, "dec_gemm: no LN variant"); dec_gemm_pick<T, DEPI_BIAS_RESID, false>(p, s); break;
+    case DEPI_LOGITS: if (ln) throw Error(OHW_E_INVALID_ARG, "dec_gemm: no LN variant"); dec_gemm_pick<T, DEPI_LOGITS, false>(p, s); break;
     default: throw Error(OHW_E_INVALID_ARG, "dec_gemm: unknown epilogue");
   }
   HIP_CHECK(hipGetLastError());

@@ -69,6 +69,12 @@ struct ohw_state {
   std::vector<hipEvent_t> prof_ev;
   size_t prof_used = 0;
   double prof_work = 0.0;
+  // hipGraph of one greedy iteration {feed sampled token, single-token decoder step, sampler}
+  hipGraph_t step_graph = nullptr;
+  hipGraphExec_t step_exec = nullptr;
+  int graph_batch = 0;
+  SamplerParams graph_spar{};
+  bool graphs_enabled = true;
   // timing
   hipEvent_t ev[6]{};
   ohw_timings last{};
@@ -85,7 +91,7 @@ struct ProfScope {
     if (st->prof_used + 2 > st->prof_ev.size()) {
       const size_t old = st->prof_ev.size();
       st->prof_ev.resize(old + 1024);
-      for (size_t i = old; i < st->prof_ev.size(); ++i) HIP_CHECK(hipEventCreate(&st->prof_ev[i]));
+      for (size_t i = old; i < st->prof_ev.size(); ++i) HIP_CHECK(hipEventCreateWithFlags(&st->prof_ev[i], hipEventDisableSystemFence));
     }
     HIP_CHECK(hipEventRecord(st->prof_ev[st->prof_used], st->stream));
     st->prof_work += work;
@@ -228,9 +234,10 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
   launch_embed<T>(c->emb.p, c->dec_pos.as<float>(), st->step_tok.as<int32_t>(), n_past, st->dx.as<float>(), M, n_new, d, s);
   const int64_t kv_layer = (int64_t)st->max_batch * H * C * 64;      // elements per K (or V) cache of one layer
   const int64_t xkv_slab = (int64_t)B * H * Tn * 64;                 // cross K/V slab (batch of the last encode)
-  auto gemm = [&](const void* x, const DevBuf& w, const DevBuf& bias, void* out, int N, int K, int epi, int64_t ld) {
+  auto gemm = [&](const void* x, const LayerNormW* ln, const DevBuf& w, const DevBuf& bias, void* out, int N, int K, int epi, int64_t ld) {
     DecGemmParams p{};
     p.x = x; p.w = w.p; p.bias = bias.p ? bias.as<float>() : nullptr; p.out = out;
+    if (ln) { p.ln_g = ln->g.as<float>(); p.ln_b = ln->b.as<float>(); }
     p.M = M; p.N = N; p.K = K; p.n_new = n_new; p.ld_out = ld; p.n_past = n_past;
     p.d_model = d; p.n_head = H; p.n_ctx = C;
     ProfScope ps(st, OHW_PROF_DEC_GEMM, 2.0 * ((double)((N + 15) / 16 * 16) * K) * ((M + 31) / 32));
@@ -240,30 +247,30 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
     const DecLayerW& w = c->dec[l];
     T* kc = (T*)st->self_kv.p + (int64_t)(2 * l) * kv_layer;
     T* vc = kc + kv_layer;
-    launch_layernorm<T>(st->dx.as<float>(), w.ln1.g.as<float>(), w.ln1.b.as<float>(), st->dy.p, M, d, s);
-    {
+    {  // LN1 + fused QKV projection; K/V go straight into the cache at each window's position
       DecGemmParams p{};
-      p.x = st->dy.p; p.w = w.wqkv.p; p.bias = w.bqkv.as<float>(); p.out = st->dq.p;
+      p.x = st->dx.p; p.ln_g = w.ln1.g.as<float>(); p.ln_b = w.ln1.b.as<float>();
+      p.w = w.wqkv.p; p.bias = w.bqkv.as<float>(); p.out = st->dq.p;
       p.M = M; p.N = 3 * d; p.K = d; p.n_new = n_new; p.ld_out = d;
       p.k_cache = kc; p.v_cache = vc; p.n_past = n_past; p.d_model = d; p.n_head = H; p.n_ctx = C;
       ProfScope ps(st, OHW_PROF_DEC_GEMM, 2.0 * (3.0 * d * d) * ((M + 31) / 32));
       launch_dec_gemm<T>(p, DEPI_QKV, s);
     }
     launch_self_attn<T>(st->dq.p, kc, vc, n_past, st->da.p, M, n_new, H, C, s);
-    gemm(st->da.p, w.wo, w.bo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
-    launch_layernorm<T>(st->dx.as<float>(), w.lnx.g.as<float>(), w.lnx.b.as<float>(), st->dy.p, M, d, s);
-    gemm(st->dy.p, w.wxq, w.bxq, st->dq.p, d, d, DEPI_BIAS_T, d);
-    ProfScope psx(st, OHW_PROF_DEC_XATTN, 2.0 * 2.0 * (double)M * H * Tn * 64.0);
-    launch_cross_attn<T>(st->dq.p, (const T*)st->xkv.p + (int64_t)(2 * l) * xkv_slab, (const T*)st->xkv.p + (int64_t)(2 * l + 1) * xkv_slab,
-                         st->da.p, M, n_new, H, Tn, s);
-    gemm(st->da.p, w.wxo, w.bxo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
-    launch_layernorm<T>(st->dx.as<float>(), w.ln2.g.as<float>(), w.ln2.b.as<float>(), st->dy.p, M, d, s);
-    gemm(st->dy.p, w.w1, w.b1, st->df.p, 4 * d, d, DEPI_BIAS_GELU_T, 4 * d);
-    gemm(st->df.p, w.w2, w.b2, st->dx.p, d, 4 * d, DEPI_BIAS_RESID, d);
+    gemm(st->da.p, nullptr, w.wo, w.bo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
+    gemm(st->dx.p, &w.lnx, w.wxq, w.bxq, st->dq.p, d, d, DEPI_BIAS_T, d);
+    {
+      ProfScope psx(st, OHW_PROF_DEC_XATTN, 2.0 * 2.0 * (double)M * H * Tn * 64.0);
+      launch_cross_attn<T>(st->dq.p, (const T*)st->xkv.p + (int64_t)(2 * l) * xkv_slab, (const T*)st->xkv.p + (int64_t)(2 * l + 1) * xkv_slab,
+                           st->da.p, M, n_new, H, Tn, s);
+    }
+    gemm(st->da.p, nullptr, w.wxo, w.bxo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
+    gemm(st->dx.p, &w.ln2, w.w1, w.b1, st->df.p, 4 * d, d, DEPI_BIAS_GELU_T, 4 * d);
+    gemm(st->df.p, nullptr, w.w2, w.b2, st->dx.p, d, 4 * d, DEPI_BIAS_RESID, d);
   }
   launch_layernorm<T>(st->dx.as<float>(), c->dec_ln.g.as<float>(), c->dec_ln.b.as<float>(), st->dy.p, M, d, s);
   DevBuf none;
-  gemm(st->dy.p, c->emb, none, st->logits.p, hp.n_vocab, d, DEPI_LOGITS, st->logits_ld);
+  gemm(st->dy.p, nullptr, c->emb, none, st->logits.p, hp.n_vocab, d, DEPI_LOGITS, st->logits_ld);
 }
 
 void fill_sampler(const ohw_state* st, const ohw_sample_params* sp, int B, SamplerParams* p) {
@@ -361,6 +368,8 @@ void ohw_state_free(ohw_state* st) {
   (void)hipDeviceSynchronize();
   for (auto& e : st->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : st->prof_ev) if (e) (void)hipEventDestroy(e);
+  if (st->step_exec) (void)hipGraphExecDestroy(st->step_exec);
+  if (st->step_graph) (void)hipGraphDestroy(st->step_graph);
   if (st->own_stream) (void)hipStreamDestroy(st->own_stream);
   delete st;
 }
@@ -493,21 +502,47 @@ int ohw_greedy(ohw_state* st, const ohw_sample_params* sp, int batch, int32_t* t
       HIP_CHECK(hipMemcpyAsync(st->n_past.p, np.data(), np.size() * 4, hipMemcpyHostToDevice, s));
       HIP_CHECK(hipStreamSynchronize(s));  // np is a stack-lifetime source
       ++steps;
+      spar.advance = 0;
+      launch_sampler(spar, s);   // first token of every window from the prompt's logits
+      spar.advance = 1;          // every later sampler call follows a single-token step
+      // One greedy iteration = {feed next_tok, decoder step, sampler}.  It is launch-bound (about 260
+      // short kernels), so it is captured once into a hipGraph and replayed; positions, tokens and
+      // the done flags live in device memory, so the same graph serves every iteration.
+      const bool use_graph = st->graphs_enabled && st->prof_class == 0 && s != nullptr;
+      if (use_graph && (!st->step_exec || st->graph_batch != batch || std::memcmp(&st->graph_spar, &spar, sizeof spar) != 0)) {
+        if (st->step_exec) { (void)hipGraphExecDestroy(st->step_exec); st->step_exec = nullptr; }
+        if (st->step_graph) { (void)hipGraphDestroy(st->step_graph); st->step_graph = nullptr; }
+        HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        try {
+          HIP_CHECK(hipMemcpyAsync(st->step_tok.p, st->next_tok.p, (size_t)batch * 4, hipMemcpyDeviceToDevice, s));
+          run_decoder_step<T>(st, batch, 1);
+          launch_sampler(spar, s);
+        } catch (...) {
+          hipGraph_t g = nullptr;
+          (void)hipStreamEndCapture(s, &g);
+          if (g) (void)hipGraphDestroy(g);
+          throw;
+        }
+        HIP_CHECK(hipStreamEndCapture(s, &st->step_graph));
+        HIP_CHECK(hipGraphInstantiate(&st->step_exec, st->step_graph, nullptr, nullptr, 0));
+        st->graph_batch = batch;
+        st->graph_spar = spar;
+      }
       int32_t n_done_host = 0;
-      for (int it = 0; it < n_max; ++it) {
-        spar.advance = it > 0 ? 1 : 0;  // account for the single-token step that produced these logits
-        launch_sampler(spar, s);
-        const bool check = sp->force_len > 0 ? (it == n_max - 1) : ((it & 7) == 7 || it == n_max - 1);
-        if (check) {
+      for (int it = 1; it < n_max; ++it) {
+        if (use_graph) {
+          HIP_CHECK(hipGraphLaunch(st->step_exec, s));
+        } else {
+          HIP_CHECK(hipMemcpyAsync(st->step_tok.p, st->next_tok.p, (size_t)batch * 4, hipMemcpyDeviceToDevice, s));
+          run_decoder_step<T>(st, batch, 1);
+          launch_sampler(spar, s);
+        }
+        ++steps;
+        if (sp->force_len <= 0 && ((it & 7) == 7)) {
           HIP_CHECK(hipMemcpyAsync(&n_done_host, st->n_done.p, 4, hipMemcpyDeviceToHost, s));
           HIP_CHECK(hipStreamSynchronize(s));
           if (n_done_host >= batch) break;
         }
-        if (it == n_max - 1) break;
-        // feed the sampled tokens: step_tok <- next_tok, positions n_past (advanced after the step)
-        HIP_CHECK(hipMemcpyAsync(st->step_tok.p, st->next_tok.p, (size_t)batch * 4, hipMemcpyDeviceToDevice, s));
-        run_decoder_step<T>(st, batch, 1);
-        ++steps;
       }
     });
     HIP_CHECK(hipEventRecord(st->ev[5], s));

@@ -43,7 +43,8 @@ enum DecEpilogue {
   DEPI_LOGITS = 4      // logits f32 [batch][ld_logits], only rows m with (m % n_new) == n_new - 1
 };
 struct DecGemmParams {
-  const void* x;       // T [M][K]
+  const void* x;       // T [M][K]; with ln_g != nullptr: f32 [M][K] residual stream, LayerNorm fused
+  const float* ln_g; const float* ln_b;
   const void* w;       // tiled T [Npad/16][K/32][64][8]
   const float* bias;   // [N] or nullptr
   void* out;           // see DecEpilogue

@@ -11,36 +11,45 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + row * d;
+  // unconditional (clamped) loads, masked arithmetic: see the note in decode.hip's fused LayerNorm
   f32x4 v[MAXV];
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = (i * 64 + lane) * 4;
-    if (c < d) { v[i] = *(const f32x4*)(xr + c); sum += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
-    else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    v[i] = *(const f32x4*)(xr + (c < d ? c : 0));
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const float ok = c < d ? 1.f : 0.f;
+    sum += ok * ((v[i].x + v[i].y) + (v[i].z + v[i].w));
   }
   const float mean = wave_sum(sum) / (float)d;
   float var = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = (i * 64 + lane) * 4;
-    if (c < d) {
-      const float a = v[i].x - mean, b2 = v[i].y - mean, c2 = v[i].z - mean, d2 = v[i].w - mean;
-      var += (a * a + b2 * b2) + (c2 * c2 + d2 * d2);
-    }
+    const float ok = c < d ? 1.f : 0.f;
+    const float a = v[i].x - mean, b2 = v[i].y - mean, c2 = v[i].z - mean, d2 = v[i].w - mean;
+    var += ok * ((a * a + b2 * b2) + (c2 * c2 + d2 * d2));
   }
   const float rstd = rsqrtf(wave_sum(var) / (float)d + 1e-5f);
   T* yr = y + row * d;
+  f32x4 g[MAXV], bb[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = (i * 64 + lane) * 4;
-    if (c < d) {
-      const f32x4 g = *(const f32x4*)(gamma + c), bb = *(const f32x4*)(beta + c);
-      u32x2 w;
-      w.x = pack2<T>((v[i].x - mean) * rstd * g.x + bb.x, (v[i].y - mean) * rstd * g.y + bb.y);
-      w.y = pack2<T>((v[i].z - mean) * rstd * g.z + bb.z, (v[i].w - mean) * rstd * g.w + bb.w);
-      *(u32x2*)(yr + c) = w;
-    }
+    g[i] = *(const f32x4*)(gamma + (c < d ? c : 0));
+    bb[i] = *(const f32x4*)(beta + (c < d ? c : 0));
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    u32x2 w;
+    w.x = pack2<T>((v[i].x - mean) * rstd * g[i].x + bb[i].x, (v[i].y - mean) * rstd * g[i].y + bb[i].y);
+    w.y = pack2<T>((v[i].z - mean) * rstd * g[i].z + bb[i].z, (v[i].w - mean) * rstd * g[i].w + bb[i].w);
+    if (c < d) *(u32x2*)(yr + c) = w;
   }
 }
 
@@ -49,7 +58,9 @@ void launch_layernorm(const float* x, const float* gamma, const float* beta, voi
   if (rows <= 0) return;
   if (d % 4 != 0 || d > 2048) throw Error(OHW_E_INVALID_ARG, "layernorm: d must be a multiple of 4 and <= 2048");
   const unsigned blocks = (unsigned)((rows + 3) / 4);
-  if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<T, 4>), dim3(blocks), dim3(256), 0, s, x, gamma, beta, (T*)y, rows, d);
+  if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(blocks), dim3(256), 0, s, x, gamma, beta, (T*)y, rows, d);
+  else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<T, 4>), dim3(blocks), dim3(256), 0, s, x, gamma, beta, (T*)y, rows, d);
+  else if (d <= 1280) hipLaunchKernelGGL((layernorm_kernel<T, 5>), dim3(blocks), dim3(256), 0, s, x, gamma, beta, (T*)y, rows, d);
   else hipLaunchKernelGGL((layernorm_kernel<T, 8>), dim3(blocks), dim3(256), 0, s, x, gamma, beta, (T*)y, rows, d);
   HIP_CHECK(hipGetLastError());
 }

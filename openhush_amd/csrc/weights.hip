@@ -10,13 +10,14 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
 }
 
 __global__ void synth_fill_kernel(float* __restrict__ dst, int64_t n, uint32_t key, float scale, float offset, int round_f16) {
-  // one rounding per operation, like numpy: no mul+add contraction (HIP's __f*_rn are plain operators)
+  // one rounding per operation, like numpy: no mul+add contraction.  The operators are written here
+  // (not through HIP's __f*_rn helpers, which are inlined WITH their own contract flags).
 #pragma clang fp contract(off)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t h = fmix32(((uint32_t)i * 0x9E3779B1u) ^ key);
-    float u = __fsub_rn(__fmul_rn((float)(h >> 8), 0x1p-23f), 1.0f);
-    float v = __fmul_rn(u, scale);
-    if (offset != 0.0f) v = __fadd_rn(v, offset);
+    const float u = (float)(h >> 8) * 0x1p-23f - 1.0f;   // exact
+    float v = u * scale;
+    if (offset != 0.0f) v = v + offset;
     if (round_f16) v = (float)(_Float16)v;
     dst[i] = v;
   }
