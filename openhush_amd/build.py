@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libohw.so")
 BUILD = os.path.join(CSRC, "_build")
-SOURCES = ["gemm.hip", "attention.hip", "weights.hip", "mel.hip", "misc.hip", "decode.hip", "model.hip", "engine.hip", "host_engine.cpp"]
+SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "weights.hip", "mel.hip", "misc.hip", "decode.hip", "model.hip", "engine.hip", "host_engine.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=fast-honor-pragmas",
          "-fno-gpu-rdc", "-x", "hip"]
 

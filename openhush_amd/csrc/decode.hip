@@ -76,6 +76,28 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
     }
   }
 
+  // fragment-tile pointers of this workgroup's n-tiles
+  const vec8* wt[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    int nt = nt0 + t;
+    if (nt > n_tiles - 1) nt = n_tiles - 1;   // ragged last workgroup: recompute the last tile, never stored
+    wt[t] = (const vec8*)p.w + (int64_t)nt * kblocks * 64 + lane;
+  }
+  // LN variants (K <= 1280: at most 5 k-blocks per wave): the whole weight share of the wave is
+  // requested BEFORE the LayerNorm prologue, so the HBM round trip overlaps the prologue's own loads
+  constexpr int UL = DG_LN_MAXK / 32 / DG_WAVES;   // 5
+  vec8 wpre[NT][UL];
+  if constexpr (LN) {
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      int kk = wave + DG_WAVES * u;
+      if (kk > kblocks - 1) kk = kblocks - 1;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wpre[t][u] = __builtin_nontemporal_load(&wt[t][(int64_t)kk * 64]);
+    }
+  }
+
   if constexpr (LN) {
     // all 512 threads: row = tid / 16, 16 threads per row, every load of the 32 x K tile in flight at once
     const float* __restrict__ xf = (const float*)p.x;
@@ -146,13 +168,6 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   const T* x1 = LN ? nullptr : x + (int64_t)r1 * p.K + (lane >> 4) * 8;
   const unsigned char* y0 = ylds + (lane & 15) * ystride + (lane >> 4) * 16;
   const unsigned char* y1 = y0 + 16 * ystride;
-  const vec8* wt[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    int nt = nt0 + t;
-    if (nt > n_tiles - 1) nt = n_tiles - 1;   // ragged last workgroup: recompute the last tile, never stored
-    wt[t] = (const vec8*)p.w + (int64_t)nt * kblocks * 64 + lane;
-  }
   f32x4 acc[NT][2];
 #pragma unroll
   for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -186,10 +201,60 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
         acc[t][1] = Ops::mfma16(w[t][u], b[u], acc[t][1]);
       }
   };
-  int kb = wave;
-  for (; kb + DG_WAVES * 9 < kblocks; kb += DG_WAVES * 10) run(std::integral_constant<int, 10>{}, kb);
-  for (; kb + DG_WAVES * 4 < kblocks; kb += DG_WAVES * 5) run(std::integral_constant<int, 5>{}, kb);
-  for (; kb < kblocks; kb += DG_WAVES) run(std::integral_constant<int, 1>{}, kb);
+  if constexpr (LN) {
+    vec8 a[UL], b[UL];
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      const int kk = wave + DG_WAVES * u;
+      const int kc = kk < kblocks ? kk : 0;
+      a[u] = *(const vec8*)(y0 + kc * 64);
+      b[u] = *(const vec8*)(y1 + kc * 64);
+      if (kk >= kblocks) {   // register select, not a load branch: blocks past K contribute zero
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[u][e] = 0; b[u][e] = 0; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UL; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t][0] = Ops::mfma16(wpre[t][u], a[u], acc[t][0]);
+        acc[t][1] = Ops::mfma16(wpre[t][u], b[u], acc[t][1]);
+      }
+  } else {
+    int kb = wave;
+    // long K (mlp.2): every weight block of the wave's share is requested at once (20 KiB per wave, one HBM
+    // round trip); the activation fragments are L2 hits and are fetched five at a time right before use
+    for (; kb + DG_WAVES * 19 < kblocks; kb += DG_WAVES * 20) {
+      constexpr int UW = 20;
+      vec8 w[NT][UW];
+#pragma unroll
+      for (int u = 0; u < UW; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[t][u] = __builtin_nontemporal_load(&wt[t][(int64_t)(kb + DG_WAVES * u) * 64]);
+#pragma unroll
+      for (int g = 0; g < UW; g += 5) {
+        vec8 a[5], b[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int kk = kb + DG_WAVES * (g + u);
+          a[u] = *(const vec8*)(x0 + kk * 32);
+          b[u] = *(const vec8*)(x1 + kk * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            acc[t][0] = Ops::mfma16(w[t][g + u], a[u], acc[t][0]);
+            acc[t][1] = Ops::mfma16(w[t][g + u], b[u], acc[t][1]);
+          }
+      }
+    }
+    for (; kb + DG_WAVES * 9 < kblocks; kb += DG_WAVES * 10) run(std::integral_constant<int, 10>{}, kb);
+    for (; kb + DG_WAVES * 4 < kblocks; kb += DG_WAVES * 5) run(std::integral_constant<int, 5>{}, kb);
+    for (; kb < kblocks; kb += DG_WAVES) run(std::integral_constant<int, 1>{}, kb);
+  }
 
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -277,48 +342,58 @@ template <typename T>
 __global__ __launch_bounds__(64) void self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
                                                        const int32_t* __restrict__ n_past, T* __restrict__ out, int n_new,
                                                        int n_head, int n_ctx) {
+  // One wave per (row, head).  Keys are processed in chunks of 64: lane j owns key (chunk*64 + j) for the
+  // score, lane = dh for P.V.  Every global load of a chunk (the lane's K row: 8 x 16 B, and the chunk's V
+  // column slice: 64 x 2 B) is requested before anything waits: one memory round trip per chunk.
   __shared__ float qs[64];
-  __shared__ float ps[448 + 64];
+  __shared__ float ps[64];
   const int lane = threadIdx.x;
   const int h = blockIdx.x, m = blockIdx.y;
   const int b = m / n_new, i = m % n_new;
   const int d = n_head * 64;
   int n_keys = n_past[b] + i + 1;
   if (n_keys > n_ctx) n_keys = n_ctx;
-  qs[lane] = (float)q[(int64_t)m * d + h * 64 + lane] * 0.125f;
-  __syncthreads();
   const T* kb = kc + (((int64_t)b * n_head + h) * n_ctx << 6);
   const T* vb = vc + (((int64_t)b * n_head + h) * n_ctx << 6);
-  float mx = -INFINITY;
-  for (int j = lane; j < n_keys; j += 64) {
-    const vec8_t<T>* kr = (const vec8_t<T>*)(kb + ((int64_t)j << 6));
+  qs[lane] = (float)q[(int64_t)m * d + h * 64 + lane] * 0.125f;
+  float m_run = -INFINITY, l_run = 0.f, o = 0.f;
+  for (int c0 = 0; c0 < n_keys; c0 += 64) {
+    const int nk = n_keys - c0 < 64 ? n_keys - c0 : 64;
+    const int jk = lane < nk ? c0 + lane : c0;          // clamped: unconditional loads
+    vec8_t<T> kr[8];
+    const vec8_t<T>* kp = (const vec8_t<T>*)(kb + ((int64_t)jk << 6));
+#pragma unroll
+    for (int c = 0; c < 8; ++c) kr[c] = kp[c];
+    T vr[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const int jj = j < nk ? c0 + j : c0;
+      vr[j] = vb[((int64_t)jj << 6) + lane];
+    }
+    __syncthreads();   // qs (first chunk) / ps of the previous chunk consumed
+    float sc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sc += qs[c * 8 + e] * (float)kr[c][e];
+    if (lane >= nk) sc = -INFINITY;
+    const float m_new = fmaxf(m_run, wave_max(sc));
+    const float alpha = __expf(m_run - m_new);
+    const float pe = lane < nk ? __expf(sc - m_new) : 0.f;
+    ps[lane] = pe;
+    l_run = l_run * alpha + wave_sum(pe);
+    m_run = m_new;
+    __syncthreads();
     float acc = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const vec8_t<T> kv = kr[c];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += qs[c * 8 + e] * (float)kv[e];
-    }
-    ps[j] = acc;
-    mx = fmaxf(mx, acc);
+    for (int j = 0; j < 64; ++j) acc += ps[j] * (float)vr[j];   // masked keys carry p = 0
+    o = o * alpha + acc;
   }
-  mx = wave_max(mx);
-  float sum = 0.f;
-  for (int j = lane; j < n_keys; j += 64) {
-    const float e = __expf(ps[j] - mx);
-    ps[j] = e;
-    sum += e;
-  }
-  sum = wave_sum(sum);
-  __syncthreads();
-  float o = 0.f;
-  for (int j = 0; j < n_keys; ++j) o += ps[j] * (float)vb[((int64_t)j << 6) + lane];
-  out[(int64_t)m * d + h * 64 + lane] = (T)(o / sum);
+  out[(int64_t)m * d + h * 64 + lane] = (T)(o / l_run);
 }
 template <typename T>
 void launch_self_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* n_past, void* out, int M, int n_new,
                       int n_head, int n_ctx, hipStream_t s) {
-  if (n_ctx > 448 + 64) throw Error(OHW_E_INVALID_ARG, "self_attn: n_text_ctx > 512 unsupported");
   hipLaunchKernelGGL((self_attn_kernel<T>), dim3(n_head, M), dim3(64), 0, s, (const T*)q, (const T*)k_cache, (const T*)v_cache, n_past,
                      (T*)out, n_new, n_head, n_ctx);
   HIP_CHECK(hipGetLastError());
@@ -367,8 +442,8 @@ __global__ __launch_bounds__(XA_THREADS) void cross_attn_kernel(const T* __restr
       int key = g * 8 + slot;
       keys[u] = (g < n_groups && key < t_len) ? key : -1;
       if (key > t_len - 1) key = t_len - 1;
-      kf[u] = *(const vec8_t<T>*)(kb + ((int64_t)key << 6));
-      vf[u] = *(const vec8_t<T>*)(vb + ((int64_t)key << 6));
+      kf[u] = __builtin_nontemporal_load((const vec8_t<T>*)(kb + ((int64_t)key << 6)));
+      vf[u] = __builtin_nontemporal_load((const vec8_t<T>*)(vb + ((int64_t)key << 6)));
     }
 #pragma unroll
     for (int u = 0; u < XA_UNROLL; ++u) {
@@ -454,21 +529,27 @@ __device__ __forceinline__ bool sp_allowed(const SamplerParams& p, const SampSta
   return true;
 }
 
-__device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  v = is_max ? wave_max(v) : wave_sum(v);
-  __syncthreads();
-  if (lane == 0) sh[w] = v;
-  __syncthreads();
-  float r = sh[0];
-  for (int i = 1; i < SP_THREADS / 64; ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
-  return r;
+struct SampAcc {
+  float m, s_all, s_ts;     // online log-sum-exp state: sums are relative to m
+  float tv; int ti;         // best text token  (value, index)
+  float zv; int zi;         // best timestamp token
+};
+
+__device__ __forceinline__ void samp_merge(SampAcc& a, const SampAcc& b) {
+  const float mn = fmaxf(a.m, b.m);
+  const float fa = a.m == -INFINITY ? 0.f : expf(a.m - mn);
+  const float fb = b.m == -INFINITY ? 0.f : expf(b.m - mn);
+  a.s_all = a.s_all * fa + b.s_all * fb;
+  a.s_ts = a.s_ts * fa + b.s_ts * fb;
+  a.m = mn;
+  if (b.tv > a.tv || (b.tv == a.tv && b.ti < a.ti)) { a.tv = b.tv; a.ti = b.ti; }
+  if (b.zv > a.zv || (b.zv == a.zv && b.zi < a.zi)) { a.zv = b.zv; a.zi = b.zi; }
 }
 
+// ONE pass over the logits row: masked online log-sum-exp (all / timestamps) and the best text and
+// best timestamp candidates; the timestamp-mass rule then only chooses between the two candidates.
 __global__ __launch_bounds__(SP_THREADS) void sampler_kernel(SamplerParams p) {
-  __shared__ float sh[SP_THREADS / 64];
-  __shared__ float shv[SP_THREADS / 64];
-  __shared__ int shi[SP_THREADS / 64];
+  __shared__ SampAcc sh[SP_THREADS / 64];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (p.done[b]) return;
   const int np_now = p.n_past[b] + p.advance;
@@ -483,49 +564,41 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_kernel(SamplerParams p) {
   for (int i = n_cur - 1; i >= 0; --i) if (toks[i] >= p.ts_begin) { st.last_seen = toks[i]; break; }
   st.suppress_eot = p.force_len > 0 && n_cur < p.force_len;
   const int V = p.n_vocab;
-  // pass 1: max over allowed logits
-  float mx = -INFINITY;
-  for (int i = tid; i < V; i += SP_THREADS) if (sp_allowed(p, st, i)) mx = fmaxf(mx, lg[i]);
-  mx = block_reduce(mx, sh, true);
-  // pass 2: sum exp (all), sum exp (timestamps), max text logit
-  float se = 0.f, sts = 0.f, tmax = -INFINITY;
+  SampAcc a;
+  a.m = -INFINITY; a.s_all = 0.f; a.s_ts = 0.f; a.tv = -INFINITY; a.ti = 0x7fffffff; a.zv = -INFINITY; a.zi = 0x7fffffff;
   for (int i = tid; i < V; i += SP_THREADS) {
+    const float v = lg[i];                     // unconditional load; masked below
     if (!sp_allowed(p, st, i)) continue;
-    const float v = lg[i];
-    const float e = expf(v - mx);
-    se += e;
-    if (i >= p.ts_begin) sts += e; else tmax = fmaxf(tmax, v);
-  }
-  se = block_reduce(se, sh, false);
-  sts = block_reduce(sts, sh, false);
-  tmax = block_reduce(tmax, sh, true);
-  const float lse = mx + logf(se);
-  bool force_ts = false;
-  if (!p.no_timestamps && sts > 0.f) {
-    const float ts_lp = mx + logf(sts) - lse;
-    const float text_lp = tmax - lse;
-    force_ts = ts_lp > text_lp;
-  }
-  // pass 3: arg-max (lowest index on ties)
-  float bv = -INFINITY; int bi = 0x7fffffff;
-  for (int i = tid; i < V; i += SP_THREADS) {
-    if (!sp_allowed(p, st, i)) continue;
-    if (force_ts && i < p.ts_begin) continue;
-    const float v = lg[i];
-    if (v > bv) { bv = v; bi = i; }
+    if (v > a.m) {
+      const float f = a.m == -INFINITY ? 0.f : expf(a.m - v);
+      a.s_all *= f; a.s_ts *= f; a.m = v;
+    }
+    const float e = expf(v - a.m);
+    a.s_all += e;
+    if (i >= p.ts_begin) { a.s_ts += e; if (v > a.zv) { a.zv = v; a.zi = i; } }
+    else if (v > a.tv) { a.tv = v; a.ti = i; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const float v2 = __shfl_xor(bv, o, 64);
-    const int i2 = __shfl_xor(bi, o, 64);
-    if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+    SampAcc bb;
+    bb.m = __shfl_xor(a.m, o, 64); bb.s_all = __shfl_xor(a.s_all, o, 64); bb.s_ts = __shfl_xor(a.s_ts, o, 64);
+    bb.tv = __shfl_xor(a.tv, o, 64); bb.ti = __shfl_xor(a.ti, o, 64); bb.zv = __shfl_xor(a.zv, o, 64); bb.zi = __shfl_xor(a.zi, o, 64);
+    samp_merge(a, bb);
   }
-  __syncthreads();
-  if ((tid & 63) == 0) { shv[tid >> 6] = bv; shi[tid >> 6] = bi; }
+  if ((tid & 63) == 0) sh[tid >> 6] = a;
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < SP_THREADS / 64; ++w)
-      if (shv[w] > bv || (shv[w] == bv && shi[w] < bi)) { bv = shv[w]; bi = shi[w]; }
+    for (int w = 1; w < SP_THREADS / 64; ++w) samp_merge(a, sh[w]);
+    const float lse = a.m + logf(a.s_all);
+    bool force_ts = false;
+    if (!p.no_timestamps && a.s_ts > 0.f) {
+      const float ts_lp = a.m + logf(a.s_ts) - lse;
+      const float text_lp = a.tv - lse;
+      force_ts = ts_lp > text_lp;
+    }
+    // arg-max over what is left; text indices are below timestamp indices, so ties go to text
+    float bv; int bi;
+    if (force_ts || a.zv > a.tv) { bv = a.zv; bi = a.zi; } else { bv = a.tv; bi = a.ti; }
     const int n_max = p.force_len > 0 ? p.force_len : p.n_max;
     bool finished = false;
     if (bi == p.eot) {

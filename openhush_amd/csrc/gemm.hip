@@ -14,6 +14,7 @@
 // written to the other LDS stage afterwards: one barrier per K-step).
 // Roofline: MFMA-bound (arithmetic intensity = 64 flop/B at this tile).
 #include "gemm.hpp"
+#include "gemm_epilogue.hpp"
 
 namespace ohw {
 
@@ -144,52 +145,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[ni * 4 + j] = acc[mi][ni][j] + bias[ni * 4 + j];
-    const int64_t b = m / p.rows_per_batch, rr = m % p.rows_per_batch;
-    if constexpr (EPI == EPI_BIAS_T || EPI == EPI_BIAS_GELU_T) {
-      if constexpr (EPI == EPI_BIAS_GELU_T) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
-      }
-      T* o = (T*)p.out + b * p.c_batch_stride + rr * p.ldc + nb;
-      u32x4 lo, hi;
-      lo.x = pack2<T>(v[0], v[1]); lo.y = pack2<T>(v[2], v[3]); lo.z = pack2<T>(v[4], v[5]); lo.w = pack2<T>(v[6], v[7]);
-      hi.x = pack2<T>(v[8], v[9]); hi.y = pack2<T>(v[10], v[11]); hi.z = pack2<T>(v[12], v[13]); hi.w = pack2<T>(v[14], v[15]);
-      *(u32x4*)o = lo;
-      *(u32x4*)(o + 8) = hi;
-    } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
-      float* o = (float*)p.out + b * p.c_batch_stride + rr * p.ldc + nb;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 old = *(const f32x4*)(o + 4 * j);
-        old.x += v[4 * j]; old.y += v[4 * j + 1]; old.z += v[4 * j + 2]; old.w += v[4 * j + 3];
-        *(f32x4*)(o + 4 * j) = old;
-      }
-    } else if constexpr (EPI == EPI_GELU_POS_F32) {
-      float* o = (float*)p.out + b * p.c_batch_stride + rr * p.ldc + nb;
-      const float* ps = p.pos + rr * p.N + nb;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 pp = *(const f32x4*)(ps + 4 * j);
-        f32x4 r;
-        r.x = gelu_erf(v[4 * j]) + pp.x; r.y = gelu_erf(v[4 * j + 1]) + pp.y;
-        r.z = gelu_erf(v[4 * j + 2]) + pp.z; r.w = gelu_erf(v[4 * j + 3]) + pp.w;
-        *(f32x4*)(o + 4 * j) = r;
-      }
-    } else if constexpr (EPI == EPI_F32) {
-      float* o = (float*)p.out + b * p.c_batch_stride + rr * p.ldc + nb;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) *(f32x4*)(o + 4 * j) = (f32x4){v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
-    } else if constexpr (EPI == EPI_CROSSKV_T) {
-      // n -> slab (layer*2 + k/v), head, dh ; out[slab][b][h][t][64]
-      const int64_t slab = nb / p.d_model, rem = nb % p.d_model;
-      const int64_t h = rem >> 6, dh = rem & 63;
-      T* o = (T*)p.out + ((((slab * p.batch + b) * p.n_head + h) * p.t_len + rr) << 6) + dh;
-      u32x4 lo, hi;
-      lo.x = pack2<T>(v[0], v[1]); lo.y = pack2<T>(v[2], v[3]); lo.z = pack2<T>(v[4], v[5]); lo.w = pack2<T>(v[6], v[7]);
-      hi.x = pack2<T>(v[8], v[9]); hi.y = pack2<T>(v[10], v[11]); hi.z = pack2<T>(v[12], v[13]); hi.w = pack2<T>(v[14], v[15]);
-      *(u32x4*)o = lo;
-      *(u32x4*)(o + 8) = hi;
-    }
+    gemm_store_row<T, EPI>(p, m, nb, v);
   }
 }
 
@@ -208,6 +164,8 @@ static void launch_one(const GemmParams& p, hipStream_t stream) {
 template <typename T>
 void launch_gemm(const GemmParams& p, int epilogue, hipStream_t stream) {
   if (p.M <= 0) return;
+  // big problems go to the 256x256 direct-to-LDS kernel (gemm256.hip); small N or small M stay here
+  if (p.N % 256 == 0 && p.M >= 1024 && p.K % 64 == 0) { launch_gemm256<T>(p, epilogue, stream); return; }
   if (p.N % BN != 0 || p.K % BK != 0 || p.lda % 8 != 0 || p.a_batch_stride % 8 != 0 || p.rows_per_batch <= 0)
     throw Error(OHW_E_INVALID_ARG, "gemm: N must be a multiple of 128, K of 64, row strides of 8 elements");
   switch (epilogue) {

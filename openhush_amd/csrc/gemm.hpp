@@ -28,5 +28,7 @@ struct GemmParams {
 
 // N % 128 == 0, K % 64 == 0, lda/ldc/strides multiples of 8 elements (16-byte rows)
 template <typename T> void launch_gemm(const GemmParams& p, int epilogue, hipStream_t stream);
+// the 256x256x64 variant (N % 256 == 0); launch_gemm dispatches to it for large problems
+template <typename T> void launch_gemm256(const GemmParams& p, int epilogue, hipStream_t stream);
 
 }  // namespace ohw

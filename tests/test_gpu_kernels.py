@@ -27,7 +27,7 @@ def _tdtype(E, dt):
 
 
 @pytest.mark.parametrize("dt", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (3000, 384, 1152), (128, 128, 64), (1, 128, 64), (4096, 1280, 1280)])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (3000, 384, 1152), (128, 128, 64), (1, 128, 64), (4096, 1280, 1280), (3000, 256, 768), (1100, 512, 64), (6000, 768, 3072)])
 def test_gemm_epilogues(E, dt, M, N, K):
     g = torch.Generator(device="cuda").manual_seed(M * 7 + N + K)
     td = _tdtype(E, dt)
