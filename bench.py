@@ -30,8 +30,9 @@ import numpy as np  # noqa: E402
 PEAK_HBM_GBS = 8000.0
 PEAK_MFMA_TFLOPS = 2500.0   # dense bf16 / f16
 
-PROF_NAMES = {1: "gemm_kernel (encoder / cross-KV MFMA GEMM)", 2: "encoder_attention_kernel", 3: "cross_attn_kernel (decoder)",
-              4: "dec_gemm_kernel (decoder weight streaming)"}
+PROF_NAMES = {1: "gemm256_kernel (encoder / cross-KV MFMA GEMM)", 2: "encoder_attention_kernel", 3: "cross_attn_kernel (decoder)",
+              4: "dec_gemm_kernel<RESID|PARTIAL> (decoder out-projections, mlp.2)", 5: "dec_gemm_kernel<QKV,LN>",
+              6: "dec_gemm_kernel<BIAS,LN> (cross query)", 7: "dec_gemm_kernel<GELU,LN> (mlp.0)", 8: "dec_gemm_kernel<LOGITS>"}
 
 
 def main():
@@ -44,8 +45,10 @@ def main():
     ap.add_argument("--tokens", type=int, default=100)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--profile-class", type=int, default=0, help="0 = pick the class with the largest total time")
+    ap.add_argument("--streams", type=int, default=1, help="split the batch over this many concurrent states/streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=0, help="decode tokens in the CPU sample (0 = same as --tokens)")
+    ap.add_argument("--cpu-windows", type=int, default=3, help="30 s windows in the CPU sample")
     args = ap.parse_args()
 
     import torch
@@ -60,39 +63,60 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ    # under torch.distributed.run the collectives run even at N = 1
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     hp = synth.PRESETS[args.model]
     dtype = E.OHW_DTYPE_BF16 if args.dtype == "bf16" else E.OHW_DTYPE_F16
     B = args.batch
     ctx = E.Context.synthetic(hp.as_list(), 1234, local_rank, dtype)
-    st = E.State(ctx, B)
-    stream = torch.cuda.current_stream()
-    st.set_stream(stream.cuda_stream)
+    # the batch may be split over several concurrent states (each with its own HIP stream): the
+    # latency-bound decoder kernels of one sub-batch then overlap the HBM-bound ones of another
+    S = max(1, args.streams)
+    if B % S != 0:
+        raise SystemExit("--batch must be divisible by --streams")
+    Bs = B // S
+    states = [E.State(ctx, Bs) for _ in range(S)]
+    st = states[0]
 
     # synthetic 16 kHz audio: window ids are global so that every rank transcribes different audio
     pcm_host = np.stack([synth.synth_audio(rank * B + b) for b in range(B)])
     pcm = torch.from_numpy(pcm_host).cuda()
-    n_samples = [synth.CHUNK_SAMPLES] * B
+    n_samples = [synth.CHUNK_SAMPLES] * Bs
     p = ctx.default_params()
     p.force_len = args.tokens
 
     dev = torch.device("cuda", local_rank)
+    import threading
+
+    def run_state(i, out):
+        s_ = states[i]
+        s_.mel_device(pcm.data_ptr() + i * Bs * pcm.shape[1] * 4, pcm.shape[1], n_samples, E.OHW_MEL_ZERO_TAIL)
+        s_.encode(Bs)
+        out[i], _ = s_.greedy(Bs, p)
 
     def step():
-        st.mel_device(pcm.data_ptr(), pcm.shape[1], n_samples, E.OHW_MEL_ZERO_TAIL)
-        st.encode(B)
-        toks, _ = st.greedy(B, p)
-        if world > 1:   # the path's only communication: token ids of every rank's windows to rank 0 (KBs, RCCL)
-            shard.gather_tokens(shard.pack_tokens(toks, args.tokens), dist, world, rank, dev)
+        out = [None] * S
+        if S == 1:
+            run_state(0, out)
+        else:   # ctypes releases the GIL inside the library: the S host threads enqueue concurrently
+            th = [threading.Thread(target=run_state, args=(i, out)) for i in range(S)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        toks = [t for o in out for t in o]
+        if use_dist:    # the path's only communication: token ids of every rank's windows to rank 0 (KBs, RCCL)
+            shard.gather_tokens(shard.pack_tokens(toks, args.tokens), dist, world, rank, dev, force=True)
         return toks
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -113,8 +137,13 @@ def main():
     # launch the same kernels eagerly; only per-kernel durations are taken from them, never `value`.
     prof_class = args.profile_class
     class_totals = {}
+    S_saved, S = S, 1          # the roofline leg runs sub-batch 0 alone, eagerly, on its own stream
+    def step():                # noqa: F811
+        out = [None]
+        run_state(0, out)
+        return out[0]
     if prof_class == 0:
-        for cls in (1, 2, 3, 4):
+        for cls in sorted(PROF_NAMES):
             st.profile_begin(cls)
             step()
             n, ms, w = st.profile_end()
@@ -126,7 +155,7 @@ def main():
     launches, k_ms, work = st.profile_end()
 
     dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
     dt_max = float(dt_t.item())
     audio_s = 30.0 * B * world * args.steps
@@ -143,25 +172,42 @@ def main():
             achieved = work / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
+        roof["traffic"] = pmc_traffic(prof_class, B)
         roof.update({"kernel": PROF_NAMES[prof_class], "launches": launches, "avg_launch_us": round(1e3 * k_ms / max(1, launches), 2),
                      "kernel_ms_per_step": round(k_ms / args.steps, 3),
                      "class_ms_per_step": {PROF_NAMES[k]: round(v, 3) for k, v in class_totals.items()}})
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(hp, pcm_host[0], args.cpu_tokens or args.tokens)
+            cpu = cpu_baseline(hp, pcm_host[:max(1, min(args.cpu_windows, B))], args.cpu_tokens or args.tokens)
         line = {
             "metric": "audio-sec/sec (xRT) large-v3 greedy, 30s chunks", "value": round(value, 1), "unit": "audio-sec/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.model} dims, batch={B} x 30 s windows per GPU, greedy, {args.tokens} tokens/window (EOT suppressed), "
                                    f"procedural weights seed 1234, PCM resident in HBM", "model_dims": hp.as_list(),
+                       "concurrent_sub_batches": S_saved,
                        "stage_ms_last_step": {"mel": round(tm.mel_ms, 2), "encode": round(tm.encode_ms, 2), "decode": round(tm.decode_ms, 2)},
                        "decode_steps": tm.decode_steps},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+
+
+def pmc_traffic(prof_class, batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_summary.json: FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE, separate passes).
+    bench.py cannot run the profiler around itself; null when no committed figure matches this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            pm = json.load(f)
+        ent = pm.get(str(prof_class))
+        if ent and ent.get("batch") == batch:
+            return ent["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def usable_cores() -> int:
@@ -197,13 +243,17 @@ def cpu_baseline(hp, pcm, n_tokens):
     p = m.default_params()
     p.force_len = n_tokens
     t0 = time.perf_counter()
-    toks, (t_mel, t_enc, t_dec) = m.transcribe_chunk(pcm, p, 1)
+    t_mel = t_enc = t_dec = 0.0
+    for w in range(len(pcm)):
+        toks, (a, b, c) = m.transcribe_chunk(pcm[w], p, 1)
+        assert len(toks) == n_tokens
+        t_mel += a; t_enc += b; t_dec += c
+        print(f"[bench] cpu_baseline: window {w + 1}/{len(pcm)} done", file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
-    assert len(toks) == n_tokens
     m.close()
-    return {"value": round(30.0 / dt, 3), "unit": "audio-sec/sec", "cores": cores, "kind": "port",
-            "sample": f"1 window (30 s) of the same workload, {n_tokens} decode tokens, fp32 C/OpenMP oracle: mel {t_mel:.2f} s, "
-                      f"encoder+crossKV {t_enc:.2f} s, decode {t_dec:.2f} s"}
+    return {"value": round(30.0 * len(pcm) / dt, 3), "unit": "audio-sec/sec", "cores": cores, "kind": "port",
+            "sample": f"{len(pcm)} windows (30 s each) of the same workload, {n_tokens} decode tokens per window, fp32 C/OpenMP oracle "
+                      f"(x86-64-v3): mel {t_mel:.2f} s, encoder+crossKV {t_enc:.2f} s, decode {t_dec:.2f} s"}
 
 
 if __name__ == "__main__":

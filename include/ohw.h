@@ -138,10 +138,12 @@ typedef struct { float mel_ms, encode_ms, decode_ms, total_ms; int32_t decode_st
 int ohw_state_timings(ohw_state* st, ohw_timings* t);
 
 /* per-kernel-class timing with HIP events on the state's stream (bench.py's roofline leg).        */
-/* Classes: 1 encoder/cross-KV MFMA GEMM, 2 encoder attention, 3 decoder cross-attention,          */
-/* 4 decoder weight-streaming GEMM.  work = algorithmic flops (1, 2) or bytes (3, 4) summed over    */
-/* the launches between begin and end.                                                             */
-enum { OHW_PROF_NONE = 0, OHW_PROF_ENC_GEMM = 1, OHW_PROF_ENC_ATTN = 2, OHW_PROF_DEC_XATTN = 3, OHW_PROF_DEC_GEMM = 4 };
+/* Classes = kernels: 1 encoder/cross-KV MFMA GEMM, 2 encoder attention, 3 decoder cross-attention, */
+/* 4..8 the instantiations of the decoder weight-streaming GEMM (residual-accumulate out-projections */
+/* and mlp.2; LN+QKV; LN+cross-query; LN+mlp.0+GELU; logits).  work = algorithmic flops (1, 2) or    */
+/* bytes (3..8) summed over the launches between begin and end.                                     */
+enum { OHW_PROF_NONE = 0, OHW_PROF_ENC_GEMM = 1, OHW_PROF_ENC_ATTN = 2, OHW_PROF_DEC_XATTN = 3, OHW_PROF_DEC_GEMM = 4,
+       OHW_PROF_DEC_GEMM_QKV = 5, OHW_PROF_DEC_GEMM_XQ = 6, OHW_PROF_DEC_GEMM_FC1 = 7, OHW_PROF_DEC_GEMM_LOGITS = 8 };
 int ohw_state_profile_begin(ohw_state* st, int kernel_class);
 int ohw_state_profile_end(ohw_state* st, int64_t* launches, double* total_ms, double* work);
 

@@ -241,7 +241,9 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
     if (ln) { p.ln_g = ln->g.as<float>(); p.ln_b = ln->b.as<float>(); }
     p.M = M; p.N = N; p.K = K; p.n_new = n_new; p.ld_out = ld; p.n_past = n_past;
     p.d_model = d; p.n_head = H; p.n_ctx = C;
-    ProfScope ps(st, OHW_PROF_DEC_GEMM, 2.0 * ((double)((N + 15) / 16 * 16) * K) * ((M + 31) / 32));
+    const int cls = epi == DEPI_BIAS_T ? OHW_PROF_DEC_GEMM_XQ : epi == DEPI_BIAS_GELU_T ? OHW_PROF_DEC_GEMM_FC1
+                  : epi == DEPI_LOGITS ? OHW_PROF_DEC_GEMM_LOGITS : OHW_PROF_DEC_GEMM;
+    ProfScope ps(st, cls, 2.0 * ((double)((N + 15) / 16 * 16) * K) * ((M + 31) / 32));
     launch_dec_gemm<T>(p, epi, s);
   };
   for (int l = 0; l < L; ++l) {
@@ -254,7 +256,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
       p.w = w.wqkv.p; p.bias = w.bqkv.as<float>(); p.out = st->dq.p;
       p.M = M; p.N = 3 * d; p.K = d; p.n_new = n_new; p.ld_out = d;
       p.k_cache = kc; p.v_cache = vc; p.n_past = n_past; p.d_model = d; p.n_head = H; p.n_ctx = C;
-      ProfScope ps(st, OHW_PROF_DEC_GEMM, 2.0 * (3.0 * d * d) * ((M + 31) / 32));
+      ProfScope ps(st, OHW_PROF_DEC_GEMM_QKV, 2.0 * (3.0 * d * d) * ((M + 31) / 32));
       launch_dec_gemm<T>(p, DEPI_QKV, s);
     }
     launch_self_attn<T>(st->dq.p, kc, vc, n_past, st->da.p, M, n_new, H, C, s);
@@ -592,7 +594,7 @@ int ohw_state_timings(ohw_state* st, ohw_timings* t) {
 int ohw_state_profile_begin(ohw_state* st, int kernel_class) {
   return guard([&] {
     if (!st) throw Error(OHW_E_INVALID_ARG, "state is null");
-    if (kernel_class < 0 || kernel_class > 4) throw Error(OHW_E_INVALID_ARG, "unknown kernel class");
+    if (kernel_class < 0 || kernel_class > 8) throw Error(OHW_E_INVALID_ARG, "unknown kernel class");
     HIP_CHECK(hipSetDevice(st->ctx->device));
     st->prof_class = kernel_class;
     st->prof_used = 0;

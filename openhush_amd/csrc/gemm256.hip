@@ -3,18 +3,21 @@
 // Same contract and epilogues as gemm.hip (C = A * W^T, swapped MFMA operands, 16 contiguous output
 // columns per lane), for the large encoder / cross-K/V GEMMs (N % 256 == 0).
 //
-// Structure (cdna_hip_programming.md section 5, "Pipelining across barriers"):
+// Structure (after cdna_hip_programming.md section 5, "Pipelining across barriers" / the 8-phase idea):
 //   * 512 threads = 8 waves (2 along m x 4 along n), each wave a 128x64 output tile = 8x4 MFMA tiles of
 //     16x16x32 (128 accumulator VGPRs); one workgroup per CU.
-//   * LDS: 2 stages x (256x64 A + 256x64 W) x 2 B = 128 KiB, ONE shared array.  Rows are 128 B; the
-//     16-byte chunks of a row are XOR-swizzled by (row & 7).  Tiles are filled by global_load_lds_dwordx4
-//     (1 KiB = 8 rows per wave-instruction): the LDS destination is lane-linear, so the swizzle is applied
-//     to the per-lane SOURCE address and to the fragment read (rule 21 of the guide).
-//   * the loads of tile t+1 stay in flight while tile t is computed: counted s_waitcnt vmcnt(8) + raw
-//     s_barrier (a __syncthreads() would drain vmcnt to 0), two barriers per K-tile:
-//         wait(tile t landed) ; barrier ; 64 MFMA per wave ; barrier ; issue loads of tile t+2.
-// Roofline: MFMA (128 flop per LDS-read byte at this wave tile; HBM traffic per flop 2x lower than the
-// 128^2 kernel).
+//   * LDS: ONE 128-KiB array = 2 stages x 2 k-halves x (256x32 A + 256x32 W) x 2 B.  A k-half buffer has
+//     64-byte rows; its four 16-byte chunks are XOR-swizzled with key[(row >> 2) & 3], key = {0,3,2,1},
+//     which makes every ds_read_b128 fragment read conflict-free (bank analysis in DESIGN.md section 5).
+//     Buffers are filled by global_load_lds_dwordx4 (1 KiB = 16 rows per wave-instruction): the LDS
+//     destination is lane-linear, so the swizzle goes on the per-lane SOURCE address and on the read.
+//   * a K-tile is computed in two halves (k 0..31, then k 32..63), 32 MFMAs per wave each.  The refill of
+//     a k-half buffer is issued INSIDE the compute phase that follows the barrier which retired its last
+//     readers, interleaved with the MFMAs, and stays in flight for ~1.5 K-tiles:
+//         start(t): vmcnt(8); barrier; [MFMA k-half 0 of tile t  ||  issue tile t+1 / k-half 1]
+//         mid(t)  : vmcnt(8); barrier; [MFMA k-half 1 of tile t  ||  issue tile t+2 / k-half 0]
+//     Counted s_waitcnt vmcnt + raw s_barrier only (a __syncthreads() would drain vmcnt to 0).
+// Roofline: MFMA.
 #include "gemm.hpp"
 #include "gemm_epilogue.hpp"
 
@@ -22,7 +25,10 @@ namespace ohw {
 
 constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
 constexpr int G2_THREADS = 512;
-constexpr int G2_STAGE = 65536;   // bytes per stage: A 32 KiB | W 32 KiB
+constexpr int G2_HALF = 32768;    // bytes per (stage, k-half): A 16 KiB | W 16 KiB
+constexpr int G2_STAGE = 2 * G2_HALF;
+
+__device__ __forceinline__ int g2_key(int row) { return (0x6C >> (((row >> 2) & 3) * 2)) & 3; }  // {0,3,2,1}
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
@@ -44,38 +50,37 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   const T* __restrict__ A = (const T*)p.A;
   const T* __restrict__ W = (const T*)p.W;
 
-  // ---- staging: wave w fills 1-KiB blocks 4w .. 4w+3 of each operand (8 rows x 128 B per block).
-  // lane -> row r = lane>>3 of the block, LDS chunk c = lane&7, which must hold data chunk c ^ r.
-  const int sr = lane >> 3, sc = lane & 7;
-  const int src_chunk = sc ^ sr;
-  const T* a_src[4];
-  const T* w_src[4];
+  // ---- staging: per k-half buffer each operand is 16 blocks of 1 KiB (16 rows x 64 B); wave w fills
+  // blocks 2w and 2w+1.  lane -> row r = lane>>2 of the block, LDS chunk c = lane&3, holding data chunk
+  // c ^ key(row).
+  const int sr = lane >> 2, sc = lane & 3;
+  const T* a_src[2];
+  const T* w_src[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int R = (wave * 4 + j) * 8 + sr;          // LDS row 0..255
+  for (int j = 0; j < 2; ++j) {
+    const int R = (wave * 2 + j) * 16 + sr;         // LDS row 0..255
+    const int dchunk = sc ^ g2_key(R);
     int64_t m = m0 + R;
     if (m > p.M - 1) m = p.M - 1;
     const int64_t b = m / p.rows_per_batch, rr = m % p.rows_per_batch;
-    a_src[j] = A + b * p.a_batch_stride + rr * p.lda + src_chunk * 8;
+    a_src[j] = A + b * p.a_batch_stride + rr * p.lda + dchunk * 8;
     // LDS row rho (inside each 64-row block: rho = ni*16 + q*4 + jj) holds W row q*16 + ni*4 + jj
     const int rl = R & 63;
     const int nl = (((rl >> 2) & 3) << 4) + ((rl >> 4) << 2) + (rl & 3);
-    w_src[j] = W + (n0 + (R & ~63) + nl) * p.K + src_chunk * 8;
+    w_src[j] = W + (n0 + (R & ~63) + nl) * p.K + dchunk * 8;
   }
   const int KT = (int)(p.K / G2_BK);
 
-  auto issue = [&](int kt, int stage) {
-    const int koff = kt * G2_BK;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + koff),
-                                       (__attribute__((address_space(3))) void*)(smem + stage * G2_STAGE + (wave * 4 + j) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + koff),
-                                       (__attribute__((address_space(3))) void*)(smem + stage * G2_STAGE + 32768 + (wave * 4 + j) * 1024), 16, 0, 0);
-    }
+  // one glds of tile kt / k-half h: q = 0,1 -> A blocks, q = 2,3 -> W blocks
+  auto issue1 = [&](int kt, int h, int q) {
+    const int koff = kt * G2_BK + h * 32;
+    const int buf = (kt & 1) * G2_STAGE + h * G2_HALF;
+    if (q < 2)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[q] + koff),
+                                       (__attribute__((address_space(3))) void*)(smem + buf + (wave * 2 + q) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[q - 2] + koff),
+                                       (__attribute__((address_space(3))) void*)(smem + buf + 16384 + (wave * 2 + (q - 2)) * 1024), 16, 0, 0);
   };
 
   f32x4 acc[8][4];
@@ -84,68 +89,68 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // fragment read offsets: row = tile row + (lane & 15); (row & 7) == (lane & 7)
-  const int fr = lane & 15, fq = lane >> 4, sw = lane & 7;
-  const int a_rd = (wm * 128 + fr) * 128;
-  const int w_rd = 32768 + (wn * 64 + fr) * 128;
+  // fragment read offsets inside a k-half buffer: row = tile row + (lane & 15), chunk (lane >> 4) ^ key(row);
+  // tile rows start at multiples of 16, so key(row) depends on (lane & 15) only
+  const int fr = lane & 15, fq = lane >> 4;
+  const int fch = (fq ^ g2_key(fr)) << 4;
+  const int a_rd = (wm * 128 + fr) * 64 + fch;
+  const int w_rd = 16384 + (wn * 64 + fr) * 64 + fch;
 
-  issue(0, 0);
-  if (KT > 1) issue(1, 1);
+  // prologue: tile 0 both halves, tile 1 k-half 0
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue1(0, 0, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue1(0, 1, q);
+  if (KT > 1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue1(1, 0, q);
+  }
 
   for (int kt = 0; kt < KT; ++kt) {
-    const int cur = (kt & 1) * G2_STAGE;
-    if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // 4 clusters of 16 MFMAs (k-substep s = c >> 1, m-half = c & 1).  The LDS fragment reads of cluster
-    // c + 1 are issued before the MFMAs of cluster c and interleaved with them, so their latency is hidden.
-    const int coff0 = ((0 * 4 + fq) ^ sw) << 4, coff1 = ((1 * 4 + fq) ^ sw) << 4;
-    vec8 fw0[4], fw1[4], fa0[4], fa1[4];
+    const bool more1 = kt + 1 < KT, more2 = kt + 2 < KT;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) fw0[ni] = *(const vec8*)(smem + cur + w_rd + ni * 2048 + coff0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa0[i] = *(const vec8*)(smem + cur + a_rd + i * 2048 + coff0);
-    // cluster 0 (s=0, half 0) | prefetch cluster 1 (s=0, half 1)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa1[i] = *(const vec8*)(smem + cur + a_rd + (4 + i) * 2048 + coff0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[i][ni] = Ops::mfma16(fw0[ni], fa0[i], acc[i][ni]);
-    __builtin_amdgcn_s_setprio(0);
-    // cluster 1 (s=0, half 1) | prefetch cluster 2 (s=1, half 0) + W fragments of s=1
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) fw1[ni] = *(const vec8*)(smem + cur + w_rd + ni * 2048 + coff1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa0[i] = *(const vec8*)(smem + cur + a_rd + i * 2048 + coff1);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[4 + i][ni] = Ops::mfma16(fw0[ni], fa1[i], acc[4 + i][ni]);
-    __builtin_amdgcn_s_setprio(0);
-    // cluster 2 (s=1, half 0) | prefetch cluster 3 (s=1, half 1)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa1[i] = *(const vec8*)(smem + cur + a_rd + (4 + i) * 2048 + coff1);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[i][ni] = Ops::mfma16(fw1[ni], fa0[i], acc[i][ni]);
-    __builtin_amdgcn_s_setprio(0);
-    // cluster 3 (s=1, half 1)
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[4 + i][ni] = Ops::mfma16(fw1[ni], fa1[i], acc[4 + i][ni]);
-    __builtin_amdgcn_s_setprio(0);
-    if (kt + 2 < KT) {
-      // every wave has finished reading this stage before anyone refills it
+    for (int h = 0; h < 2; ++h) {
+      // groups of 4 glds issued after the buffer about to be read:
+      //   h = 0: (kt).h1 and, if it exists, (kt+1).h0        h = 1: (kt+1).h0 and (kt+1).h1, if they exist
+      if (h == 0) {
+        if (more1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        if (more1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      // also retires this wave's LDS reads of the previous phase before anyone refills that buffer
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      issue(kt + 2, kt & 1);
+      const int cur = (kt & 1) * G2_STAGE + h * G2_HALF;
+      // what this phase refills: h = 0 -> tile kt+1 / k-half 1 ; h = 1 -> tile kt+2 / k-half 0
+      const bool fill = h == 0 ? more1 : more2;
+      const int fkt = h == 0 ? kt + 1 : kt + 2, fh = h == 0 ? 1 : 0;
+      vec8 fw[4], fa0[4], fa1[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) fw[ni] = *(const vec8*)(smem + cur + w_rd + ni * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa0[i] = *(const vec8*)(smem + cur + a_rd + i * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa1[i] = *(const vec8*)(smem + cur + a_rd + (4 + i) * 1024);
+      // the refill is issued in two halves in front of the two MFMA clusters; while one wave of a SIMD
+      // issues its DMA the other keeps the MFMA pipe busy.  (Measured alternatives, same shapes: all four
+      // glds between the clusters, or the second A-fragment group pinned behind the first MFMAs with
+      // sched_barrier: both 4 % slower.)
+      if (fill) { issue1(fkt, fh, 0); issue1(fkt, fh, 1); }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[i][ni] = Ops::mfma16(fw[ni], fa0[i], acc[i][ni]);
+      __builtin_amdgcn_s_setprio(0);
+      if (fill) { issue1(fkt, fh, 2); issue1(fkt, fh, 3); }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[4 + i][ni] = Ops::mfma16(fw[ni], fa1[i], acc[4 + i][ni]);
+      __builtin_amdgcn_s_setprio(0);
     }
   }
 

@@ -32,9 +32,10 @@ def unpack_tokens(packed: torch.Tensor) -> List[List[int]]:
     return [[int(x) for x in row[1:1 + int(row[0])]] for row in p]
 
 
-def gather_tokens(packed: torch.Tensor, dist, world: int, rank: int, device: Optional[torch.device] = None):
-    """All ranks send their packed tokens to rank 0; returns the list of per-rank tensors there."""
-    if world == 1:
+def gather_tokens(packed: torch.Tensor, dist, world: int, rank: int, device: Optional[torch.device] = None, force: bool = False):
+    """All ranks send their packed tokens to rank 0; returns the list of per-rank tensors there.
+    force=True runs the collective even for a single rank (rehearsal of the N > 1 path on one GPU)."""
+    if world == 1 and not force:
         return [packed]
     t = packed.to(device) if device is not None else packed
     bufs = [torch.zeros_like(t) for _ in range(world)] if rank == 0 else None
