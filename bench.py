@@ -68,6 +68,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # keep stdout to the ONE JSON line: RCCL prints a version banner there when NCCL_DEBUG is VERSION/INFO
+        if "OHW_NCCL_DEBUG" in os.environ:
+            os.environ["NCCL_DEBUG"] = os.environ["OHW_NCCL_DEBUG"]
+        else:
+            os.environ.pop("NCCL_DEBUG", None)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     hp = synth.PRESETS[args.model]
@@ -190,7 +195,8 @@ def main():
                        "decode_steps": tm.decode_steps},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
 
