@@ -256,3 +256,63 @@ def test_engine_error_paths(E, tmp_path):
     with pytest.raises(E.LoadFailed) as ei:
         E.WhisperEngine.new(str(bad), "auto", False, False)   # device = "cpu": no CPU path exists
     assert ei.value.code == E.OHW_E_NO_GPU
+
+
+def test_tiny_dims_use_both_gemm_kernels(E, oracle, tmp_models):
+    """tiny (d = 384, 4 layers, 6 heads): N = 384 / 1152 run on the 128x128 GEMM, N = 1536 on the 256x256 one."""
+    path = tmp_models("tiny")
+    om = oracle.Model.load(path)
+    ctx = E.Context.from_file(path, 0, E.OHW_DTYPE_F16)
+    st = E.State(ctx, 2)
+    pcm = np.stack([synth.synth_audio(31), synth.synth_audio(32)])
+    mel = st.mel(pcm, None, E.OHW_MEL_REFLECT)
+    st.encode(2)
+    enc = st.fetch("enc", 2)
+    p = ctx.default_params(); p.n_max = 24
+    toks, _ = st.greedy(2, p)
+    op = om.default_params(); op.n_max = 24
+    for b in range(2):
+        ref_enc = om.encode(om.log_mel(pcm[b], 0))
+        assert np.abs(mel[b] - om.log_mel(pcm[b], 0)).max() < 2e-4
+        assert np.abs(enc[b] - ref_enc).max() < 2 * TOL_ACT[1]
+        s = oracle.State(om)
+        s.set_encoder_output(ref_enc)
+        ref, _, margins, _ = s.greedy(op)
+        k = next((i for i in range(min(len(ref), len(toks[b]))) if ref[i] != toks[b][i]), None)
+        assert k is None or margins[k] < 2 * TOL_LOGIT[1], (b, k, ref, toks[b])
+
+
+def test_large_v3_dims_one_window_matches_oracle(E, oracle):
+    """The bench's own model (large-v3 dimensions, procedural weights, bf16) against the fp32 oracle:
+    encoder output and the logits of a few teacher-forced steps for one 30 s window."""
+    hp = synth.PRESETS["large-v3"]
+    oracle.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    om = oracle.Model.synth(hp.as_list(), 1234)
+    ctx = E.Context.synthetic(hp.as_list(), 1234, 0, E.OHW_DTYPE_BF16)
+    st = E.State(ctx, 1)
+    pcm = synth.synth_audio(0)[None]
+    mel = st.mel(pcm, None, E.OHW_MEL_ZERO_TAIL)
+    st.encode(1)
+    ref_mel = om.log_mel(pcm[0], 1)
+    assert np.abs(mel[0] - ref_mel).max() < 2e-4
+    ref_enc = om.encode(ref_mel)
+    enc = st.fetch("enc", 1)[0]
+    # 32 layers of bf16 GEMM operands: compare relative to the activation scale (LayerNorm output, O(1))
+    err = np.abs(enc - ref_enc)
+    assert err.max() < 0.25 and err.mean() < 0.02, (err.max(), err.mean())
+    s = oracle.State(om)
+    s.set_encoder_output(ref_enc)
+    prompt = [ctx.tok.sot, ctx.tok.sot + 1, ctx.tok.transcribe]
+    ref = s.decode(prompt, 0)
+    got = st.decode(np.asarray([prompt], np.int32), [0])[0]
+    sig = float(ref.std())
+    assert np.abs(got - ref).max() < 0.12 * sig, (np.abs(got - ref).max(), sig)
+    tok = int(ref.argmax())
+    margin = float(np.sort(ref)[-1] - np.sort(ref)[-2])
+    assert int(got.argmax()) == tok or margin < 0.12 * sig
+    for i in range(3):
+        ref = s.decode([tok], 3 + i)
+        got = st.decode(np.asarray([[tok]], np.int32), [3 + i])[0]
+        assert np.abs(got - ref).max() < 0.12 * sig
+        tok = int(ref.argmax())
+    om.close()
