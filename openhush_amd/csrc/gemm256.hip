@@ -11,12 +11,11 @@
 //     which makes every ds_read_b128 fragment read conflict-free (bank analysis in DESIGN.md section 5).
 //     Buffers are filled by global_load_lds_dwordx4 (1 KiB = 16 rows per wave-instruction): the LDS
 //     destination is lane-linear, so the swizzle goes on the per-lane SOURCE address and on the read.
-//   * a K-tile is computed in two halves (k 0..31, then k 32..63), 32 MFMAs per wave each.  The refill of
-//     a k-half buffer is issued INSIDE the compute phase that follows the barrier which retired its last
-//     readers, interleaved with the MFMAs, and stays in flight for ~1.5 K-tiles:
-//         start(t): vmcnt(8); barrier; [MFMA k-half 0 of tile t  ||  issue tile t+1 / k-half 1]
-//         mid(t)  : vmcnt(8); barrier; [MFMA k-half 1 of tile t  ||  issue tile t+2 / k-half 0]
-//     Counted s_waitcnt vmcnt + raw s_barrier only (a __syncthreads() would drain vmcnt to 0).
+//   * a K-tile is consumed in two phases (k 0..31, then k 32..63), 32 MFMAs per wave each.  The two waves of
+//     a SIMD are staggered by one barrier interval: one reads its fragments for the next phase while the
+//     other runs MFMAs on fragments already in registers.  The refill of a buffer is issued right after the
+//     barrier that retired its last readers and stays in flight for three phase-times behind a counted
+//     s_waitcnt vmcnt(8) + raw s_barrier (a __syncthreads() would drain vmcnt to 0).
 // Roofline: MFMA.
 #include "gemm.hpp"
 #include "gemm_epilogue.hpp"
@@ -96,61 +95,83 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   const int a_rd = (wm * 128 + fr) * 64 + fch;
   const int w_rd = 16384 + (wn * 64 + fr) * 64 + fch;
 
-  // prologue: tile 0 both halves, tile 1 k-half 0
+  // A "phase" P = 2*kt + h consumes k-half h of K-tile kt (32 MFMAs per wave) from buffer P & 3, filled by
+  // glds group G(P) (4 wave-instructions per thread).
+  //
+  // The two waves that share a SIMD (wave w and w + 4, i.e. wm = 0 / 1) run the SAME program shifted by one
+  // barrier interval: in every interval one of them issues its 12 fragment reads for the next phase while
+  // the other runs the 32 MFMAs of the fragments it read one interval earlier, so the MFMA pipe of a SIMD
+  // always has a wave with operands in registers (MI355X_MICROARCH.md "Two waves per SIMD", item 9):
+  //     interval i, wave group g (0/1), j = i - g:   j even -> read phase j/2      j odd -> compute phase j/2
+  // Buffer P & 3 is read in intervals 2P (group 0) and 2P + 1 (group 1) and refilled with G(P + 4): each wave
+  // issues its share in its own next READ interval (2P + 2 for group 0, 2P + 3 for group 1), never while it
+  // computes; the data is needed again in interval 2P + 8: the DMA has 2.5-3 phase-times to land, behind a
+  // counted vmcnt(8) (two younger groups stay in flight).
+  const int NP = 2 * KT;
+  auto issue_group = [&](int P) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) issue1(0, 0, q);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) issue1(0, 1, q);
-  if (KT > 1) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) issue1(1, 0, q);
-  }
+    for (int q = 0; q < 4; ++q) issue1(P >> 1, P & 1, q);
+  };
+  issue_group(0);
+  if (NP > 1) issue_group(1);
+  if (NP > 2) issue_group(2);
 
-  for (int kt = 0; kt < KT; ++kt) {
-    const bool more1 = kt + 1 < KT, more2 = kt + 2 < KT;
+  vec8 fw[4], fa[8];
+  auto read_frags = [&](int P) {
+    const int cur = (P & 3) * G2_HALF;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      // groups of 4 glds issued after the buffer about to be read:
-      //   h = 0: (kt).h1 and, if it exists, (kt+1).h0        h = 1: (kt+1).h0 and (kt+1).h1, if they exist
-      if (h == 0) {
-        if (more1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      } else {
-        if (more1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      // also retires this wave's LDS reads of the previous phase before anyone refills that buffer
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      const int cur = (kt & 1) * G2_STAGE + h * G2_HALF;
-      // what this phase refills: h = 0 -> tile kt+1 / k-half 1 ; h = 1 -> tile kt+2 / k-half 0
-      const bool fill = h == 0 ? more1 : more2;
-      const int fkt = h == 0 ? kt + 1 : kt + 2, fh = h == 0 ? 1 : 0;
-      vec8 fw[4], fa0[4], fa1[4];
+    for (int ni = 0; ni < 4; ++ni) fw[ni] = *(const vec8*)(smem + cur + w_rd + ni * 1024);
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) fw[ni] = *(const vec8*)(smem + cur + w_rd + ni * 1024);
+    for (int mi = 0; mi < 8; ++mi) fa[mi] = *(const vec8*)(smem + cur + a_rd + mi * 1024);
+  };
+  auto compute = [&]() {
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa0[i] = *(const vec8*)(smem + cur + a_rd + i * 1024);
+    for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa1[i] = *(const vec8*)(smem + cur + a_rd + (4 + i) * 1024);
-      // the refill is issued in two halves in front of the two MFMA clusters; while one wave of a SIMD
-      // issues its DMA the other keeps the MFMA pipe busy.  (Measured alternatives, same shapes: all four
-      // glds between the clusters, or the second A-fragment group pinned behind the first MFMAs with
-      // sched_barrier: both 4 % slower.)
-      if (fill) { issue1(fkt, fh, 0); issue1(fkt, fh, 1); }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[i][ni] = Ops::mfma16(fw[ni], fa0[i], acc[i][ni]);
-      __builtin_amdgcn_s_setprio(0);
-      if (fill) { issue1(fkt, fh, 2); issue1(fkt, fh, 3); }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[4 + i][ni] = Ops::mfma16(fw[ni], fa1[i], acc[4 + i][ni]);
-      __builtin_amdgcn_s_setprio(0);
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Ops::mfma16(fw[ni], fa[mi], acc[mi][ni]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // barrier that opens an EVEN interval 2*Pn: every wave's share of G(Pn) must have landed (each wave has
+  // exactly two younger groups in flight at this point, whichever group it belongs to)
+  auto open_even = [&](int Pn) {   // (the refill itself is issued by each wave in its own READ interval)
+    if (Pn < NP) {
+      if (Pn + 2 < NP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (Pn + 1 < NP) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto open_odd = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if (wm == 0) {
+    // group 0: interval 2P reads phase P, interval 2P+1 computes it
+    for (int P = 0; P < NP; ++P) {
+      open_even(P);
+      read_frags(P);
+      if (P + 3 < NP) issue_group(P + 3);   // buffer of phase P - 1: its readers are behind the barrier above
+      __builtin_amdgcn_sched_barrier(0);
+      open_odd();
+      compute();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    open_even(NP);   // the partner group's last compute interval
+  } else {
+    // group 1: one interval behind: interval 2P+1 reads phase P, interval 2P+2 computes it
+    open_even(0);
+    for (int P = 0; P < NP; ++P) {
+      open_odd();
+      read_frags(P);
+      if (P + 3 < NP) issue_group(P + 3);   // this wave's share, one interval after the partner group's
+      __builtin_amdgcn_sched_barrier(0);
+      open_even(P + 1);
+      compute();
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 

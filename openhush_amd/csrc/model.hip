@@ -82,11 +82,29 @@ struct Placer {
   }
 
   void allocate() {
+    // two passes over the same list: size the arena, then hand out 256-byte aligned views
+    size_t total = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      size_t off = 0;
+      if (pass == 1) {
+        c->arena.alloc(total, true);
+        c->weight_bytes = total;
+      }
+      auto A = [&](DevBuf& b, size_t bytes, bool = false) {
+        const size_t sz = (bytes + 255) / 256 * 256;
+        if (pass == 1) b.view((char*)c->arena.p + off, bytes);
+        off += sz;
+      };
+      layout(A);
+      total = off;
+    }
+  }
+
+  template <typename Alloc>
+  void layout(Alloc&& A) {
     const ohw_hparams& hp = c->hp;
     const int64_t d = hp.n_audio_state, dt = hp.n_text_state, L = hp.n_text_layer;
     const size_t e = 2;
-    size_t total = 0;
-    auto A = [&](DevBuf& b, size_t bytes, bool zero = false) { b.alloc(bytes, zero); total += bytes; };
     A(c->conv1_w, (size_t)d * 3 * MEL_CPAD * e); A(c->conv1_b, (size_t)d * 4);
     A(c->conv2_w, (size_t)d * 3 * d * e); A(c->conv2_b, (size_t)d * 4);
     A(c->enc_pos, (size_t)hp.n_audio_ctx * d * 4);
@@ -114,7 +132,6 @@ struct Placer {
       A(l.w2, (size_t)4 * dt * dt * e); A(l.b2, dt * 4);
     }
     A(c->dec_ln.g, dt * 4); A(c->dec_ln.b, dt * 4);
-    c->weight_bytes = total;
   }
 
   // returns false for names the engine does not use

@@ -11,14 +11,16 @@ namespace ohw {
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  bool owned = true;   // false: a view into an arena (ohw_ctx::arena), never freed here
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), owned(o.owned) { o.p = nullptr; o.bytes = 0; }
   DevBuf& operator=(DevBuf&& o) noexcept {
-    if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; owned = o.owned; o.p = nullptr; o.bytes = 0; }
     return *this;
   }
+  void view(void* ptr, size_t n) { release(); p = ptr; bytes = n; owned = false; }
   ~DevBuf() { release(); }
   void alloc(size_t n, bool zero = false) {
     release();
@@ -28,7 +30,8 @@ struct DevBuf {
     if (zero) HIP_CHECK(hipMemset(p, 0, n));
   }
   void release() {
-    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    if (p && owned) (void)hipFree(p);
+    p = nullptr; bytes = 0; owned = true;
   }
   template <typename U> U* as() const { return (U*)p; }
 };
@@ -70,4 +73,7 @@ struct ohw_ctx {
   ohw::LayerNormW dec_ln;
   int64_t v_pad = 0;
   size_t weight_bytes = 0;
+  // every weight buffer above is a view into this one allocation: one contiguous, large-fragment mapping
+  // (the decoder touches all 1.8 GB once per step; per-tensor allocations cost a TLB miss train per kernel)
+  ohw::DevBuf arena;
 };
