@@ -4,6 +4,9 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <stdexcept>
 #include <string>
 
@@ -25,6 +28,19 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
   }
 }
 #define HIP_CHECK(x) ::ohw::hip_check((x), #x, __FILE__, __LINE__)
+
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): function attributes are per device, and one
+// process may own engines on several GPUs.
+inline void ensure_dynamic_lds(const void* func, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  hip_check(hipGetDevice(&dev), "hipGetDevice", __FILE__, __LINE__);
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({func, dev})) return;
+  hip_check(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "hipFuncSetAttribute", __FILE__, __LINE__);
+  done.insert({func, dev});
+}
 
 // 16-bit storage types of the compute path
 using bf16_t = __bf16;

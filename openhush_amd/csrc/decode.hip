@@ -59,10 +59,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt0 = blockIdx.x * NT;
   const int m0 = blockIdx.y * 32;
-  const int kblocks_all = p.K / 32;
-  // split-K (DEPI_PARTIAL): this workgroup owns k-blocks [kb_lo, kb_lo + kblocks)
-  const int kblocks = EPI == DEPI_PARTIAL ? kblocks_all / p.k_split : kblocks_all;
-  const int kb_lo = EPI == DEPI_PARTIAL ? (int)blockIdx.z * kblocks : 0;
+  const int kblocks = p.K / 32;
   const int ystride = p.K * 2 + 16;
   const int n_tiles = (p.N + 15) / 16;
 
@@ -85,7 +82,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   for (int t = 0; t < NT; ++t) {
     int nt = nt0 + t;
     if (nt > n_tiles - 1) nt = n_tiles - 1;   // ragged last workgroup: recompute the last tile, never stored
-    wt[t] = (const vec8*)p.w + ((int64_t)nt * kblocks_all + kb_lo) * 64 + lane;
+    wt[t] = (const vec8*)p.w + (int64_t)nt * kblocks * 64 + lane;
   }
   // LN variants (K <= 1280: at most 5 k-blocks per wave): the whole weight share of the wave is
   // requested BEFORE the LayerNorm prologue, so the HBM round trip overlaps the prologue's own loads
@@ -167,8 +164,8 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   int r0 = m0 + (lane & 15), r1 = m0 + 16 + (lane & 15);
   if (r0 > p.M - 1) r0 = p.M - 1;
   if (r1 > p.M - 1) r1 = p.M - 1;
-  const T* x0 = LN ? nullptr : x + (int64_t)r0 * p.K + kb_lo * 32 + (lane >> 4) * 8;
-  const T* x1 = LN ? nullptr : x + (int64_t)r1 * p.K + kb_lo * 32 + (lane >> 4) * 8;
+  const T* x0 = LN ? nullptr : x + (int64_t)r0 * p.K + (lane >> 4) * 8;
+  const T* x1 = LN ? nullptr : x + (int64_t)r1 * p.K + (lane >> 4) * 8;
   const unsigned char* y0 = ylds + (lane & 15) * ystride + (lane >> 4) * 16;
   const unsigned char* y1 = y0 + 16 * ystride;
   f32x4 acc[NT][2];
@@ -226,7 +223,8 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
       }
   } else {
     int kb = wave;
-    // long K (mlp.2): every weight block of the wave's share is requested at once (20 KiB per wave, one HBM
+    // long K (mlp.2; one CU pulls its 160 KiB at ~17 GB/s, which is why this is the slowest of the small GEMMs: a
+    // 4-way split-K variant with an ordered combine kernel was measured at the same 15 us and dropped): every weight block of the wave's share is requested at once (20 KiB per wave, one HBM
     // round trip); the activation fragments are L2 hits and are fetched five at a time right before use
     for (; kb + DG_WAVES * 19 < kblocks; kb += DG_WAVES * 20) {
       constexpr int UW = 20;
@@ -277,9 +275,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
     const int m = e_m;
     if (m >= p.M || n >= p.N || nt0 + t >= n_tiles) continue;
     if (p.bias) v += p.bias[n];
-    if constexpr (EPI == DEPI_PARTIAL) {
-      ((float*)p.out)[((int64_t)blockIdx.z * p.M + m) * p.ld_out + n] = v;
-    } else if constexpr (EPI == DEPI_QKV) {
+    if constexpr (EPI == DEPI_QKV) {
       const int d = p.d_model;
       if (n < d) {
         ((T*)p.out)[(int64_t)m * d + n] = (T)v;
@@ -306,13 +302,9 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
 template <typename T, int EPI, bool LN, int NT>
 static void dec_gemm_launch(const DecGemmParams& p, hipStream_t s) {
   const int n_tiles = (p.N + 15) / 16;
-  dim3 grid((n_tiles + NT - 1) / NT, (p.M + 31) / 32, EPI == DEPI_PARTIAL ? p.k_split : 1);
+  dim3 grid((n_tiles + NT - 1) / NT, (p.M + 31) / 32);
   const size_t smem = (size_t)DG_WAVES * NT * 2 * 64 * 16 + (LN ? (size_t)32 * (p.K * 2 + 16) : 0);
-  static bool attr_set = false;
-  if (LN && !attr_set) {
-    HIP_CHECK(hipFuncSetAttribute((const void*)dec_gemm_kernel<T, EPI, LN, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  if (LN) ensure_dynamic_lds((const void*)dec_gemm_kernel<T, EPI, LN, NT>, 160 * 1024);
   hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, LN, NT>), grid, dim3(DG_THREADS), smem, s, p);
 }
 
@@ -334,35 +326,9 @@ void launch_dec_gemm(const DecGemmParams& p, int epilogue, hipStream_t s) {
     case DEPI_BIAS_T: if (ln) dec_gemm_pick<T, DEPI_BIAS_T, true>(p, s); else dec_gemm_pick<T, DEPI_BIAS_T, false>(p, s); break;
     case DEPI_BIAS_GELU_T: if (ln) dec_gemm_pick<T, DEPI_BIAS_GELU_T, true>(p, s); else dec_gemm_pick<T, DEPI_BIAS_GELU_T, false>(p, s); break;
     case DEPI_BIAS_RESID: if (ln) throw Error(OHW_E_INVALID_ARG, "dec_gemm: no LN variant"); dec_gemm_pick<T, DEPI_BIAS_RESID, false>(p, s); break;
-    case DEPI_PARTIAL:
-      if (ln || p.k_split < 1 || (p.K / 32) % p.k_split != 0 || p.bias) throw Error(OHW_E_INVALID_ARG, "dec_gemm: bad split-K request");
-      dec_gemm_pick<T, DEPI_PARTIAL, false>(p, s);
-      break;
     case DEPI_LOGITS: if (ln) throw Error(OHW_E_INVALID_ARG, "dec_gemm: no LN variant"); dec_gemm_pick<T, DEPI_LOGITS, false>(p, s); break;
     default: throw Error(OHW_E_INVALID_ARG, "dec_gemm: unknown epilogue");
   }
-  HIP_CHECK(hipGetLastError());
-}
-
-__global__ void dec_combine_kernel(float* __restrict__ x, const float* __restrict__ slabs, const float* __restrict__ bias, int M, int N,
-                                   int k_split) {
-  const int64_t n4 = (int64_t)M * N / 4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    f32x4 v = *(const f32x4*)(x + 4 * i);
-    const f32x4 b = *(const f32x4*)(bias + (4 * i) % N);
-    f32x4 acc = *(const f32x4*)(slabs + 4 * i);
-    for (int s = 1; s < k_split; ++s) {   // fixed slice order: bitwise reproducible
-      const f32x4 t = *(const f32x4*)(slabs + (int64_t)s * M * N + 4 * i);
-      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-    }
-    v.x += acc.x + b.x; v.y += acc.y + b.y; v.z += acc.z + b.z; v.w += acc.w + b.w;
-    *(f32x4*)(x + 4 * i) = v;
-  }
-}
-void launch_dec_combine(float* x, const float* slabs, const float* bias, int M, int N, int k_split, hipStream_t s) {
-  if (N % 4 != 0) throw Error(OHW_E_INVALID_ARG, "dec_combine: N must be a multiple of 4");
-  const int64_t n4 = (int64_t)M * N / 4;
-  hipLaunchKernelGGL(dec_combine_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, slabs, bias, M, N, k_split);
   HIP_CHECK(hipGetLastError());
 }
 

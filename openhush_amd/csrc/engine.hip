@@ -60,7 +60,7 @@ struct ohw_state {
   // decoder
   DevBuf xkv;      // T [2L][B][H][1500][64]
   DevBuf self_kv;  // T [L][2][B][H][n_text_ctx][64]
-  DevBuf dx, dy, dq, da, df, logits, dslab;
+  DevBuf dx, dy, dq, da, df, logits;
   DevBuf step_tok, n_past, tokens, n_cur, next_tok, done, n_done, sum_lp;
   int m_max = 0;
   int64_t logits_ld = 0;
@@ -140,7 +140,6 @@ void state_alloc(ohw_state* st) {
   st->dq.alloc((size_t)st->m_max * dt * 2);
   st->da.alloc((size_t)st->m_max * dt * 2);
   st->df.alloc((size_t)st->m_max * 4 * dt * 2);
-  st->dslab.alloc((size_t)4 * st->m_max * dt * 4);   // split-K partial sums of mlp.2
   st->logits_ld = c->v_pad;
   st->logits.alloc((size_t)B * st->logits_ld * 4);
   st->max_tokens = hp.n_text_ctx;
@@ -269,17 +268,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
     }
     gemm(st->da.p, nullptr, w.wxo, w.bxo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
     gemm(st->dx.p, &w.ln2, w.w1, w.b1, st->df.p, 4 * d, d, DEPI_BIAS_GELU_T, 4 * d);
-    // mlp.2 (K = 4d, the largest weight of the layer): 16 output rows x K is too much for one CU to
-    // stream, so K is split over 4 workgroups per n-tile and a tiny kernel adds the partial sums in order
-    if ((4 * d / 32) % 4 == 0) {
-      DecGemmParams p{};
-      p.x = st->df.p; p.w = w.w2.p; p.out = st->dslab.p; p.M = M; p.N = d; p.K = 4 * d; p.n_new = n_new; p.ld_out = d; p.k_split = 4;
-      p.n_past = n_past; p.d_model = d; p.n_head = H; p.n_ctx = C;
-      { ProfScope ps(st, OHW_PROF_DEC_GEMM, 2.0 * d * 4.0 * d * ((M + 31) / 32)); launch_dec_gemm<T>(p, DEPI_PARTIAL, s); }
-      launch_dec_combine(st->dx.as<float>(), st->dslab.as<float>(), w.b2.as<float>(), M, d, 4, s);
-    } else {
-      gemm(st->df.p, nullptr, w.w2, w.b2, st->dx.p, d, 4 * d, DEPI_BIAS_RESID, d);
-    }
+    gemm(st->df.p, nullptr, w.w2, w.b2, st->dx.p, d, 4 * d, DEPI_BIAS_RESID, d);
   }
   launch_layernorm<T>(st->dx.as<float>(), c->dec_ln.g.as<float>(), c->dec_ln.b.as<float>(), st->dy.p, M, d, s);
   DevBuf none;

@@ -152,11 +152,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
 template <typename T, int EPI>
 static void launch_one(const GemmParams& p, hipStream_t stream) {
   const unsigned nwg = (unsigned)((p.N / BN) * ((p.M + BM - 1) / BM));
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    attr_set = true;
-  }
+  ensure_dynamic_lds((const void*)gemm_kernel<T, EPI>, 65536);
   hipLaunchKernelGGL((gemm_kernel<T, EPI>), dim3(nwg), dim3(GEMM_THREADS), 65536, stream, p);
   HIP_CHECK(hipGetLastError());
 }

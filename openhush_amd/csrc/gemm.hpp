@@ -24,6 +24,7 @@ struct GemmParams {
   int64_t ldc, c_batch_stride;  // output row m at out + (m / rows_per_batch) * c_batch_stride + (m % rows_per_batch) * ldc
   // EPI_CROSSKV_T
   int32_t d_model, n_head, t_len, batch;
+  int32_t group_m;    // gemm256: m-tiles per L2-locality group (set by the launcher)
 };
 
 // N % 128 == 0, K % 64 == 0, lda/ldc/strides multiples of 8 elements (16-byte rows)

@@ -17,6 +17,8 @@
 //     barrier that retired its last readers and stays in flight for three phase-times behind a counted
 //     s_waitcnt vmcnt(8) + raw s_barrier (a __syncthreads() would drain vmcnt to 0).
 // Roofline: MFMA.
+#include <cstdlib>
+
 #include "gemm.hpp"
 #include "gemm_epilogue.hpp"
 
@@ -43,8 +45,15 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   const unsigned n_tiles_m = (unsigned)((p.M + G2_BM - 1) / G2_BM);
   const unsigned nwg = n_tiles_n * n_tiles_m;
   const unsigned lid = xcd_remap(blockIdx.x, nwg);
-  const int64_t m0 = (int64_t)(lid / n_tiles_n) * G2_BM;
-  const int64_t n0 = (int64_t)(lid % n_tiles_n) * G2_BN;
+  // tile order inside an XCD's contiguous range: groups of 8 m-tiles, m fastest, so that the ~32 workgroups
+  // an XCD runs at a time cover 8 m-tiles x 4 n-tiles (12 operand panels through its 4-MiB L2 instead of 17)
+  const unsigned GM = (unsigned)p.group_m;
+  const unsigned per_group = GM * n_tiles_n;
+  const unsigned grp_id = lid / per_group, in_grp = lid % per_group;
+  const unsigned g_first = grp_id * GM;
+  const unsigned g_size = n_tiles_m - g_first < GM ? n_tiles_m - g_first : GM;
+  const int64_t m0 = (int64_t)(g_first + in_grp % g_size) * G2_BM;
+  const int64_t n0 = (int64_t)(in_grp / g_size) * G2_BN;
 
   const T* __restrict__ A = (const T*)p.A;
   const T* __restrict__ W = (const T*)p.W;
@@ -196,12 +205,11 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
 template <typename T, int EPI>
 static void launch256_one(const GemmParams& p, hipStream_t stream) {
   const unsigned nwg = (unsigned)((p.N / G2_BN) * ((p.M + G2_BM - 1) / G2_BM));
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm256_kernel<T, EPI>), dim3(nwg), dim3(G2_THREADS), 2 * G2_STAGE, stream, p);
+  ensure_dynamic_lds((const void*)gemm256_kernel<T, EPI>, 2 * G2_STAGE);
+  GemmParams q = p;
+  static const int gm_env = [] { const char* e = getenv("OHW_GEMM_GM"); return e ? atoi(e) : 0; }();
+  q.group_m = gm_env > 0 ? gm_env : 8;
+  hipLaunchKernelGGL((gemm256_kernel<T, EPI>), dim3(nwg), dim3(G2_THREADS), 2 * G2_STAGE, stream, q);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -40,7 +40,6 @@ enum DecEpilogue {
   DEPI_BIAS_T = 1,     // out T [M][N]
   DEPI_BIAS_GELU_T = 2,
   DEPI_BIAS_RESID = 3, // x f32 [M][N] += v + bias
-  DEPI_PARTIAL = 5,    // split-K: raw fp32 partial sums to slab[blockIdx.z][M][N] (no bias); combined by launch_dec_combine
   DEPI_LOGITS = 4      // logits f32 [batch][ld_logits], only rows m with (m % n_new) == n_new - 1
 };
 struct DecGemmParams {
@@ -55,12 +54,8 @@ struct DecGemmParams {
   const int32_t* n_past;            // device [B]
   int32_t d_model, n_head, n_ctx;
   int64_t ld_out;
-  int32_t k_split;     // DEPI_PARTIAL: number of K slices (grid.z)
 };
 template <typename T> void launch_dec_gemm(const DecGemmParams& p, int epilogue, hipStream_t s);
-
-// x[m][n] += bias[n] + sum_s slab[s][m][n] in slice order (deterministic split-K combine)
-void launch_dec_combine(float* x, const float* slabs, const float* bias, int M, int N, int k_split, hipStream_t s);
 
 // x f32 [M][d] = token_embedding[tok[m]] + pos_emb[n_past[m / n_new] + m % n_new]
 template <typename T> void launch_embed(const void* emb_tiled, const float* pos, const int32_t* tok, const int32_t* n_past,
