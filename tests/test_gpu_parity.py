@@ -316,3 +316,61 @@ def test_large_v3_dims_one_window_matches_oracle(E, oracle):
         assert np.abs(got - ref).max() < 0.12 * sig
         tok = int(ref.argmax())
     om.close()
+
+
+def test_silence_short_and_empty_windows(E, oracle, models):
+    """Edge inputs: 2 s of zeros (what benchmark() feeds, reference src/engine/whisper.rs:341-353), 0.1 s of
+    audio, and a window with no samples at all, in one ragged batch."""
+    _, _, om, ctxs = models
+    st = E.State(ctxs[1], 3)
+    pcm = np.zeros((3, 32000), np.float32)
+    pcm[1, :1600] = synth.synth_audio(9, 1600)
+    ns = [32000, 1600, 0]
+    for mode in (E.OHW_MEL_REFLECT, E.OHW_MEL_ZERO_TAIL):
+        mel = st.mel(pcm, ns, mode)
+        for b in range(3):
+            ref = om.log_mel(pcm[b, :ns[b]], mode)
+            assert np.abs(mel[b] - ref).max() < 2e-4, (mode, b)
+    assert np.all(mel[0] == mel[0][0, 0]) and abs(float(mel[0][0, 0]) + 1.5) < 1e-6   # log10(1e-10) -> (-10 + 4) / 4
+    st.encode(3)
+    enc = st.fetch("enc", 3)
+    p = ctxs[1].default_params(); p.n_max = 6
+    toks, _ = st.greedy(3, p)
+    op = om.default_params(); op.n_max = 6
+    for b in range(3):
+        ref_enc = om.encode(om.log_mel(pcm[b, :ns[b]], E.OHW_MEL_ZERO_TAIL))
+        assert np.abs(enc[b] - ref_enc).max() < 2 * TOL_ACT[1]
+        s = oracle.State(om); s.set_encoder_output(ref_enc)
+        ref, _, margins, _ = s.greedy(op)
+        k = next((i for i in range(min(len(ref), len(toks[b]))) if ref[i] != toks[b][i]), None)
+        assert k is None or margins[k] < 2 * TOL_LOGIT[1]
+
+
+def test_decode_with_ragged_positions_and_long_prompt(E, oracle, models):
+    """Windows of one batch sit at different decoder positions; up to 8 tokens can be fed per call."""
+    _, _, om, ctxs = models
+    ctx = ctxs[1]
+    pcm, ns = _pcm_batch()
+    st = E.State(ctx, 3)
+    mel = st.mel(pcm, ns, E.OHW_MEL_REFLECT)
+    st.encode(3)
+    ost = []
+    for b in range(3):
+        s = oracle.State(om); s.set_encoder_output(om.encode(mel[b])); ost.append(s)
+    prompt = [ctx.tok.sot, ctx.tok.sot + 1, ctx.tok.transcribe, ctx.tok.timestamp_begin, 11, 12, 13, 14]
+    lg = st.decode(np.tile(np.asarray(prompt, np.int32), (3, 1)), [0, 0, 0])
+    ref = [s.decode(prompt, 0) for s in ost]
+    tol = TOL_LOGIT[1]
+    for b in range(3):
+        assert np.abs(lg[b] - ref[b]).max() < tol
+    # window 0 advances to position 9, window 1 re-decodes position 8 with another token, window 2 position 5
+    lg = st.decode(np.asarray([[21]], np.int32).repeat(3, 0), [8, 8, 8])
+    lg = st.decode(np.asarray([[31], [32], [33]], np.int32), [9, 8, 5])
+    ost[0].decode([21], 8)
+    want = [ost[0].decode([31], 9), ost[1].decode([32], 8), ost[2].decode([33], 5)]
+    for b in range(3):
+        assert np.abs(lg[b] - want[b]).max() < tol, b
+    with pytest.raises(E.TranscriptionFailed):
+        st.decode(np.zeros((3, 9), np.int32), [0, 0, 0])          # more than 8 tokens per call
+    with pytest.raises(E.TranscriptionFailed):
+        st.decode(np.zeros((3, 1), np.int32), [448, 0, 0])        # past n_text_ctx
