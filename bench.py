@@ -31,7 +31,7 @@ PEAK_HBM_GBS = 8000.0
 PEAK_MFMA_TFLOPS = 2500.0   # dense bf16 / f16
 
 PROF_NAMES = {1: "gemm256_kernel (encoder / cross-KV MFMA GEMM)", 2: "encoder_attention_kernel", 3: "cross_attn_kernel (decoder)",
-              4: "dec_gemm_kernel<RESID|PARTIAL> (decoder out-projections, mlp.2)", 5: "dec_gemm_kernel<QKV,LN>",
+              4: "dec_gemm_kernel<RESID> (decoder out-projections, mlp.2)", 5: "dec_gemm_kernel<QKV,LN>",
               6: "dec_gemm_kernel<BIAS,LN> (cross query)", 7: "dec_gemm_kernel<GELU,LN> (mlp.0)", 8: "dec_gemm_kernel<LOGITS>"}
 
 

@@ -113,37 +113,46 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void encoder_attention_kernel(const
         sacc[kt] = Ops::mfma32(kf, qf[ks], sacc[kt]);
       }
     }
-    // scale, mask, block max
+    // block max on the raw scores (the scale is positive); only the last key block needs the tail mask
     const int key0 = kb * ATT_KB;
+    if (key0 + ATT_KB > t_len) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          sacc[kt][r] = key < t_len ? sacc[kt][r] : -INFINITY;
+        }
+    }
     float bmax = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        float s = sacc[kt][r] * sc;
-        s = key < t_len ? s : -INFINITY;
-        sacc[kt][r] = s;
-        bmax = fmaxf(bmax, s);
-      }
+      for (int r = 0; r < 16; ++r) bmax = fmaxf(bmax, sacc[kt][r]);
     bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
-    const float m_new = fmaxf(m_run, bmax);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    const float m_new = fmaxf(m_run, bmax);          // raw-score units
+    // rescale only when some row's running max actually grew (rare after the first blocks); the branch is
+    // wave-uniform, and alpha == 1 exactly on the skipped path
+    if (!__all(m_new == m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+      m_run = m_new;
+    }
+    const float m_sc = m_run * sc;
     float psum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(sacc[kt][r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][r], sc, -m_sc));   // exp2(-inf) = 0 for masked keys
         sacc[kt][r] = pv;
         psum += pv;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    l_run += psum;
 
     // O^T += V^T P^T : 4 k-steps of 16 keys, 2 dh tiles
 #pragma unroll
