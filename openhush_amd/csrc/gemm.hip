@@ -53,7 +53,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
     const int r = srow + 32 * i;
     int64_t m = m0 + r;
     if (m > p.M - 1) m = p.M - 1;
-    const int64_t b = m / p.rows_per_batch, rr = m % p.rows_per_batch;
+    int64_t b = 0, rr = m;
+    if (p.rows_per_batch < p.M) { const unsigned bb = (unsigned)m / (unsigned)p.rows_per_batch; b = bb; rr = m - (int64_t)bb * p.rows_per_batch; }
     a_ptr[i] = A + b * p.a_batch_stride + rr * p.lda + chunk * 8;
     a_lds[i] = r * 128 + ((chunk ^ (r & 7)) << 4);
     w_ptr[i] = W + (n0 + r) * p.K + chunk * 8;
@@ -162,7 +163,7 @@ void launch_gemm(const GemmParams& p, int epilogue, hipStream_t stream) {
   if (p.M <= 0) return;
   // big problems go to the 256x256 direct-to-LDS kernel (gemm256.hip); small N or small M stay here
   if (p.N % 256 == 0 && p.M >= 1024 && p.K % 64 == 0) { launch_gemm256<T>(p, epilogue, stream); return; }
-  if (p.N % BN != 0 || p.K % BK != 0 || p.lda % 8 != 0 || p.a_batch_stride % 8 != 0 || p.rows_per_batch <= 0)
+  if (p.N % BN != 0 || p.K % BK != 0 || p.lda % 8 != 0 || p.a_batch_stride % 8 != 0 || p.rows_per_batch <= 0 || p.M >= ((int64_t)1 << 31) || p.N >= ((int64_t)1 << 31))
     throw Error(OHW_E_INVALID_ARG, "gemm: N must be a multiple of 128, K of 64, row strides of 8 elements");
   switch (epilogue) {
     case EPI_BIAS_T: launch_one<T, EPI_BIAS_T>(p, stream); break;

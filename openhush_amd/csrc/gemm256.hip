@@ -70,7 +70,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
     const int dchunk = sc ^ g2_key(R);
     int64_t m = m0 + R;
     if (m > p.M - 1) m = p.M - 1;
-    const int64_t b = m / p.rows_per_batch, rr = m % p.rows_per_batch;
+    int64_t b = 0, rr = m;
+    if (p.rows_per_batch < p.M) { const unsigned bb = (unsigned)m / (unsigned)p.rows_per_batch; b = bb; rr = m - (int64_t)bb * p.rows_per_batch; }
     a_src[j] = A + b * p.a_batch_stride + rr * p.lda + dchunk * 8;
     // LDS row rho (inside each 64-row block: rho = ni*16 + q*4 + jj) holds W row q*16 + ni*4 + jj
     const int rl = R & 63;
@@ -216,7 +217,7 @@ static void launch256_one(const GemmParams& p, hipStream_t stream) {
 template <typename T>
 void launch_gemm256(const GemmParams& p, int epilogue, hipStream_t stream) {
   if (p.M <= 0) return;
-  if (p.N % G2_BN != 0 || p.K % G2_BK != 0 || p.lda % 8 != 0 || p.a_batch_stride % 8 != 0 || p.rows_per_batch <= 0)
+  if (p.N % G2_BN != 0 || p.K % G2_BK != 0 || p.lda % 8 != 0 || p.a_batch_stride % 8 != 0 || p.rows_per_batch <= 0 || p.M >= ((int64_t)1 << 31) || p.N >= ((int64_t)1 << 31))
     throw Error(OHW_E_INVALID_ARG, "gemm256: N must be a multiple of 256, K of 64, row strides of 8 elements");
   switch (epilogue) {
     case EPI_BIAS_T: launch256_one<T, EPI_BIAS_T>(p, stream); break;

@@ -7,7 +7,9 @@ namespace ohw {
 
 template <typename T, int EPI>
 __device__ __forceinline__ void gemm_store_row(const GemmParams& p, int64_t m, int64_t nb, float (&v)[16]) {
-  const int64_t b = m / p.rows_per_batch, rr = m % p.rows_per_batch;
+  // 64-bit division is ~100 instructions on the GPU and this runs once per output row per lane
+  int64_t b = 0, rr = m;
+  if (p.rows_per_batch < p.M) { const unsigned bb = (unsigned)m / (unsigned)p.rows_per_batch; b = bb; rr = m - (int64_t)bb * p.rows_per_batch; }
   if constexpr (EPI == EPI_BIAS_T || EPI == EPI_BIAS_GELU_T) {
     if constexpr (EPI == EPI_BIAS_GELU_T) {
 #pragma unroll
