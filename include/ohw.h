@@ -93,6 +93,7 @@ void ohw_state_free(ohw_state* st); /* WhisperState drop: frees all device memor
 /* HIP stream (hipStream_t) every later call on this state enqueues on; NULL = the state's own    */
 int ohw_state_set_stream(ohw_state* st, void* hip_stream);
 int ohw_state_max_batch(const ohw_state* st);
+const ohw_ctx* ohw_state_ctx(const ohw_state* st);
 
 /* ---- the stages of state.full() (reference src/engine/whisper.rs:266-268), split so that the   */
 /*      host keeps windowing and sampling (BASELINE.json north_star) ------------------------------ */
@@ -107,6 +108,12 @@ int ohw_encode(ohw_state* st, int batch);
 /* feed tokens[b][0..n_new) at positions n_past[b].. and return logits of the last fed position    */
 /* per window: logits_out [batch][n_vocab] f32 (host).  tokens: [batch][n_new] row-major.          */
 int ohw_decode(ohw_state* st, const int32_t* tokens, int n_new, const int32_t* n_past, int batch, float* logits_out);
+
+/* language identification for the windows of the last ohw_encode (whisper.cpp whisper_lang_auto_detect: one
+ * decoder step on [sot], soft-max over the language tokens only).  lang_ids_out [batch];
+ * lang_probs_out [batch][n_langs] or NULL.  The reference never enables auto-detection ("auto" keeps
+ * whisper.cpp's default "en": SURVEY.md section 0 item 6); this entry point exists for SURVEY.md row A4.8. */
+int ohw_detect_language(ohw_state* st, int batch, int32_t* lang_ids_out, float* lang_probs_out);
 
 /* sampling parameters: the whisper.cpp defaults the reference inherits because it sets none     */
 /* (reference src/engine/whisper.rs:243-263)                                 */
@@ -158,6 +165,13 @@ int ohw_engine_new(const char* model_path, const char* language, int translate, 
 int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32_t sample_rate,
                           char* text_buf, size_t text_cap, char* language_out, uint64_t* duration_ms,
                           ohw_audio_info* info);
+/* How audio longer than 30 s is windowed.  FIXED (default): host-side cuts every 30 s, windows batched
+ * (BASELINE.json north_star).  SEEK: whisper.cpp's sequential loop as recalled (unpinned): the
+ * next window starts at the last timestamp token of the previous one (seek += 2 * (ts - ts_begin) frames of
+ * 10 ms, or 3000 when no timestamp was produced), tokens after that timestamp are dropped and re-decoded;
+ * stops when less than 1 s is left.  One window at a time, so batch = 1. */
+enum { OHW_WINDOW_FIXED = 0, OHW_WINDOW_SEEK = 1 };
+int ohw_engine_set_window_mode(ohw_engine* e, int mode);
 /* tokens of the last transcribe, per 30 s window concatenated (for parity tests)                  */
 int ohw_engine_last_tokens(ohw_engine* e, const int32_t** tokens, int* n);
 /* WhisperEngine::benchmark(safety_margin) — reference :334-387                                    */

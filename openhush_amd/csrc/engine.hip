@@ -384,6 +384,7 @@ int ohw_state_set_stream(ohw_state* st, void* hip_stream) {
 }
 
 int ohw_state_max_batch(const ohw_state* st) { return st ? st->max_batch : 0; }
+const ohw_ctx* ohw_state_ctx(const ohw_state* st) { return st ? st->ctx : nullptr; }
 
 int ohw_mel(ohw_state* st, const float* pcm, int64_t pcm_stride, const int32_t* n_samples, int batch, int pcm_on_device,
             int mel_mode, float* mel_out) {

@@ -24,6 +24,7 @@
 namespace ohw {
 extern thread_local std::string g_last_error;
 }
+extern "C" const ohw_ctx* ohw_state_ctx(const ohw_state* st);
 using namespace ohw;
 
 namespace {
@@ -58,6 +59,7 @@ struct ohw_engine {
   std::string language;
   bool translate = false;
   int max_batch = 1;
+  int window_mode = OHW_WINDOW_FIXED;
   std::vector<int32_t> last_tokens;
 };
 
@@ -158,6 +160,32 @@ int32_t ohw_sample_greedy_host(const ohw_ctx* ctx, const ohw_sample_params* p, f
   return best;
 }
 
+int ohw_detect_language(ohw_state* st, int batch, int32_t* lang_ids_out, float* lang_probs_out) {
+  return guard([&] {
+    if (!st || !lang_ids_out || batch < 1) throw Error(OHW_E_INVALID_ARG, "bad argument");
+    const ohw_ctx* ctx = ohw_state_ctx(st);
+    const ohw_special_tokens& t = ctx->tok;
+    if (ctx->hp.n_vocab < 51865) throw Error(OHW_E_INVALID_ARG, "language detection needs a multilingual model");
+    const int V = ctx->hp.n_vocab, nl = t.n_langs;
+    std::vector<int32_t> toks((size_t)batch, t.sot), past((size_t)batch, 0);
+    std::vector<float> logits((size_t)batch * V);
+    const int rc = ohw_decode(st, toks.data(), 1, past.data(), batch, logits.data());
+    if (rc != OHW_OK) throw Error(rc, g_last_error);
+    for (int b = 0; b < batch; ++b) {
+      const float* lg = logits.data() + (size_t)b * V + t.sot + 1;
+      float mx = -INFINITY;
+      int best = 0;
+      for (int i = 0; i < nl; ++i) if (lg[i] > mx) { mx = lg[i]; best = i; }
+      lang_ids_out[b] = best;
+      if (lang_probs_out) {
+        double sum = 0.0;
+        for (int i = 0; i < nl; ++i) sum += std::exp((double)(lg[i] - mx));
+        for (int i = 0; i < nl; ++i) lang_probs_out[(size_t)b * nl + i] = (float)(std::exp((double)(lg[i] - mx)) / sum);
+      }
+    }
+  });
+}
+
 int ohw_engine_new(const char* model_path, const char* language, int translate, int use_gpu, int device, int dtype, int max_batch,
                    ohw_engine** out) {
   return guard([&] {
@@ -231,29 +259,53 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
     const ohw_special_tokens& tk = e->ctx->tok;
     if (sp.lang_id >= tk.n_langs) throw Error(OHW_E_TRANSCRIBE, "language is not supported by this model");
 
-    // host-side windowing: fixed 30 s cuts (BASELINE.json north_star)
-    const int64_t n_win = (n + CHUNK_SAMPLES - 1) / CHUNK_SAMPLES;
     e->last_tokens.clear();
     std::string text;
     const int max_tok = e->ctx->hp.n_text_ctx;
-    std::vector<int32_t> toks((size_t)e->max_batch * max_tok), ntok((size_t)e->max_batch), ns((size_t)e->max_batch);
-    for (int64_t w0 = 0; w0 < n_win; w0 += e->max_batch) {
-      const int B = (int)std::min<int64_t>(e->max_batch, n_win - w0);
-      for (int b = 0; b < B; ++b) ns[(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + b) * CHUNK_SAMPLES);
-      int rc = ohw_mel(e->state, samples + w0 * CHUNK_SAMPLES, CHUNK_SAMPLES, ns.data(), B, 0, OHW_MEL_ZERO_TAIL, nullptr);
-      if (rc == OHW_OK) rc = ohw_encode(e->state, B);
-      if (rc == OHW_OK) rc = ohw_greedy(e->state, &sp, B, toks.data(), ntok.data(), max_tok, nullptr);
-      if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: " + g_last_error);   // reference :266-268
-      for (int b = 0; b < B; ++b)
-        for (int i = 0; i < ntok[(size_t)b]; ++i) {
-          const int32_t id = toks[(size_t)b * max_tok + i];
-          e->last_tokens.push_back(id);
-          if (id < tk.eot) {                                                  // segment text = text tokens only (:271-279)
-            const char* s = nullptr;
-            const int len = ohw_token_text(e->ctx, id, &s);
-            text.append(s, (size_t)len);
-          }
+    auto append_text = [&](const int32_t* t, int n) {
+      for (int i = 0; i < n; ++i) {
+        e->last_tokens.push_back(t[i]);
+        if (t[i] < tk.eot) {                                                // segment text = text tokens only (:271-279)
+          const char* sp_ = nullptr;
+          const int len = ohw_token_text(e->ctx, t[i], &sp_);
+          text.append(sp_, (size_t)len);
         }
+      }
+    };
+    if (e->window_mode == OHW_WINDOW_SEEK) {
+      // whisper.cpp's seek loop as recalled: sequential windows, advanced by the last timestamp
+      std::vector<int32_t> toks((size_t)max_tok);
+      int32_t ntok = 0;
+      const int64_t seek_end = n / HOP;               // 10 ms frames
+      int64_t seek = 0;
+      while (seek + 100 < seek_end) {
+        const int64_t off = seek * HOP;
+        const int32_t ns1 = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - off);
+        int rc = ohw_mel(e->state, samples + off, CHUNK_SAMPLES, &ns1, 1, 0, OHW_MEL_ZERO_TAIL, nullptr);
+        if (rc == OHW_OK) rc = ohw_encode(e->state, 1);
+        if (rc == OHW_OK) rc = ohw_greedy(e->state, &sp, 1, toks.data(), &ntok, max_tok, nullptr);
+        if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: " + g_last_error);
+        int64_t seek_delta = 100 * 30;                // a full window when no timestamp was produced
+        int result_len = ntok;
+        for (int i = 0; i < ntok; ++i)
+          if (toks[(size_t)i] > tk.timestamp_begin) { seek_delta = 2 * (int64_t)(toks[(size_t)i] - tk.timestamp_begin); result_len = i + 1; }
+        if (seek_delta <= 0) seek_delta = 100 * 30;
+        append_text(toks.data(), result_len);
+        seek += seek_delta;
+      }
+    } else {
+      // host-side windowing: fixed 30 s cuts (BASELINE.json north_star)
+      const int64_t n_win = (n + CHUNK_SAMPLES - 1) / CHUNK_SAMPLES;
+      std::vector<int32_t> toks((size_t)e->max_batch * max_tok), ntok((size_t)e->max_batch), ns((size_t)e->max_batch);
+      for (int64_t w0 = 0; w0 < n_win; w0 += e->max_batch) {
+        const int B = (int)std::min<int64_t>(e->max_batch, n_win - w0);
+        for (int b = 0; b < B; ++b) ns[(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + b) * CHUNK_SAMPLES);
+        int rc = ohw_mel(e->state, samples + w0 * CHUNK_SAMPLES, CHUNK_SAMPLES, ns.data(), B, 0, OHW_MEL_ZERO_TAIL, nullptr);
+        if (rc == OHW_OK) rc = ohw_encode(e->state, B);
+        if (rc == OHW_OK) rc = ohw_greedy(e->state, &sp, B, toks.data(), ntok.data(), max_tok, nullptr);
+        if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: " + g_last_error);   // reference :266-268
+        for (int b = 0; b < B; ++b) append_text(&toks[(size_t)b * max_tok], ntok[(size_t)b]);
+      }
     }
     // reference :282-283: trim
     const size_t b0 = text.find_first_not_of(" \t\r\n");
@@ -273,6 +325,12 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
     if (duration_ms)
       *duration_ms = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
   });
+}
+
+int ohw_engine_set_window_mode(ohw_engine* e, int mode) {
+  if (!e || (mode != OHW_WINDOW_FIXED && mode != OHW_WINDOW_SEEK)) return OHW_E_INVALID_ARG;
+  e->window_mode = mode;
+  return OHW_OK;
 }
 
 int ohw_engine_last_tokens(ohw_engine* e, const int32_t** tokens, int* n) {

@@ -27,6 +27,7 @@ CHUNK_FRAMES = 3000
 
 OHW_DTYPE_BF16, OHW_DTYPE_F16 = 0, 1
 OHW_MEL_REFLECT, OHW_MEL_ZERO_TAIL = 0, 1
+OHW_WINDOW_FIXED, OHW_WINDOW_SEEK = 0, 1
 EPI_BIAS_T, EPI_BIAS_GELU_T, EPI_BIAS_RESID_F32, EPI_F32 = 0, 1, 2, 4
 
 OHW_E_MODEL_NOT_FOUND, OHW_E_LOAD_FAILED, OHW_E_TRANSCRIBE = -3001, -3002, -3003
@@ -65,7 +66,7 @@ EXPORTS = [
     "ohw_default_sample_params", "ohw_sample_greedy_host", "ohw_greedy", "ohw_state_timings", "ohw_engine_new",
     "ohw_engine_transcribe", "ohw_engine_last_tokens", "ohw_engine_benchmark", "ohw_engine_free", "ohw_engine_state",
     "ohw_engine_ctx", "ohw_lang_id_to_code", "ohw_lang_code_to_id", "ohw_last_error", "ohw_abi_version", "ohw_state_fetch",
-    "ohw_dbg_gemm", "ohw_dbg_attention", "ohw_state_profile_begin", "ohw_state_profile_end", "ohw_ctx_weight_digest",
+    "ohw_dbg_gemm", "ohw_dbg_attention", "ohw_state_profile_begin", "ohw_state_profile_end", "ohw_ctx_weight_digest", "ohw_detect_language", "ohw_state_ctx", "ohw_engine_set_window_mode",
 ]
 
 
@@ -123,6 +124,9 @@ def lib():
         L.ohw_state_max_batch.argtypes = [vp]
         L.ohw_mel.argtypes = [vp, vp, C.c_int64, ip, C.c_int, C.c_int, C.c_int, fp]
         L.ohw_encode.argtypes = [vp, C.c_int]
+        L.ohw_detect_language.argtypes = [vp, C.c_int, ip, fp]
+        L.ohw_state_ctx.argtypes = [vp]
+        L.ohw_state_ctx.restype = vp
         L.ohw_decode.argtypes = [vp, ip, C.c_int, ip, C.c_int, fp]
         L.ohw_default_sample_params.argtypes = [vp, C.POINTER(SampleParams)]
         L.ohw_default_sample_params.restype = None
@@ -132,6 +136,7 @@ def lib():
         L.ohw_engine_new.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.ohw_engine_transcribe.argtypes = [vp, fp, C.c_int64, C.c_uint32, C.c_char_p, C.c_size_t, C.c_char_p,
                                             C.POINTER(C.c_uint64), C.POINTER(AudioInfo)]
+        L.ohw_engine_set_window_mode.argtypes = [vp, C.c_int]
         L.ohw_engine_last_tokens.argtypes = [vp, C.POINTER(ip), C.POINTER(C.c_int)]
         L.ohw_engine_benchmark.argtypes = [vp, C.c_float, fp, fp, fp]
         L.ohw_engine_free.argtypes = [vp]
@@ -302,6 +307,13 @@ class State:
     def encode(self, batch: int):
         _check(lib().ohw_encode(self.h, batch))
 
+    def detect_language(self, batch: int):
+        """(lang_ids [B], probs [B][n_langs]) for the windows of the last encode"""
+        ids = np.zeros(batch, dtype=np.int32)
+        probs = np.zeros((batch, self.ctx.tok.n_langs), dtype=np.float32)
+        _check(lib().ohw_detect_language(self.h, batch, _ip(ids), _fp(probs)))
+        return ids, probs
+
     def decode(self, tokens: np.ndarray, n_past: Sequence[int]) -> np.ndarray:
         """tokens [B][n_new] -> logits [B][n_vocab] of the last fed position"""
         t = np.ascontiguousarray(np.atleast_2d(tokens), dtype=np.int32)
@@ -433,6 +445,10 @@ class WhisperEngine:
         if rc != 0:
             _raise(rc, info)
         return TranscriptionResult(buf.value.decode("utf-8", "replace"), lang.value.decode(), int(ms.value))
+
+    def set_window_mode(self, mode: int):
+        """OHW_WINDOW_FIXED (0, default) or OHW_WINDOW_SEEK (1, whisper.cpp's timestamp-driven loop)"""
+        _check(lib().ohw_engine_set_window_mode(self.h, mode))
 
     def last_tokens(self) -> List[int]:
         p = C.POINTER(C.c_int32)()

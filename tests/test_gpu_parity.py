@@ -374,3 +374,60 @@ def test_decode_with_ragged_positions_and_long_prompt(E, oracle, models):
         st.decode(np.zeros((3, 9), np.int32), [0, 0, 0])          # more than 8 tokens per call
     with pytest.raises(E.TranscriptionFailed):
         st.decode(np.zeros((3, 1), np.int32), [448, 0, 0])        # past n_text_ctx
+
+
+def test_language_detection_matches_oracle(E, oracle, models):
+    """whisper.cpp's auto-detect step: [sot] at position 0, soft-max over the language tokens."""
+    _, _, om, ctxs = models
+    ctx = ctxs[1]
+    pcm, ns = _pcm_batch()
+    st = E.State(ctx, 3)
+    mel = st.mel(pcm, ns, E.OHW_MEL_REFLECT)
+    st.encode(3)
+    ids, probs = st.detect_language(3)
+    for b in range(3):
+        s = oracle.State(om); s.set_encoder_output(om.encode(mel[b]))
+        lg = s.decode([om.tok_sot], 0)[om.tok_sot + 1: om.tok_sot + 1 + om.n_langs].astype(np.float64)
+        ref = np.exp(lg - lg.max()); ref /= ref.sum()
+        assert abs(probs[b].sum() - 1.0) < 1e-4 and np.abs(probs[b] - ref).max() < 0.02
+        top2 = np.sort(lg)[-2:]
+        assert ids[b] == int(lg.argmax()) or top2[1] - top2[0] < 2 * TOL_LOGIT[1]
+    assert E.lang_id_to_code(int(ids[0])) != ""
+
+
+def test_seek_window_mode_matches_restated_loop(E, oracle, models):
+    """OHW_WINDOW_SEEK: whisper.cpp's timestamp-driven window loop (unpinned), restated here in
+    Python around the oracle: seek += 2 * (last timestamp - ts_begin), tokens after it dropped, stop below 1 s."""
+    preset, path, om, _ = models
+    eng = E.WhisperEngine.new(path, "en", False, True, 0, E.OHW_DTYPE_F16, 1)
+    eng.set_window_mode(E.OHW_WINDOW_SEEK)
+    pcm = np.concatenate([synth.synth_audio(41), synth.synth_audio(42, 200000)])
+    res = eng.transcribe(E.AudioBuffer(pcm, 16000))
+    got = eng.last_tokens()
+    ref, seek, seek_end, first_margin_problem = [], 0, len(pcm) // 160, None
+    op = om.default_params()
+    n_windows = 0
+    while seek + 100 < seek_end:
+        win = pcm[seek * 160: seek * 160 + 480000]
+        s = oracle.State(om)
+        s.set_encoder_output(om.encode(om.log_mel(win, 1)))
+        toks, _, margins, _ = s.greedy(op)
+        delta, rlen = 3000, len(toks)
+        for i, t in enumerate(toks):
+            if t > om.tok_beg:
+                delta, rlen = 2 * (t - om.tok_beg), i + 1
+        if len(got) >= len(ref) + rlen and got[len(ref):len(ref) + rlen] != toks[:rlen] and first_margin_problem is None:
+            k = next(i for i in range(rlen) if got[len(ref) + i] != toks[i])
+            first_margin_problem = float(margins[k])
+        ref += toks[:rlen]
+        seek += delta if delta > 0 else 3000
+        n_windows += 1
+        if first_margin_problem is not None:
+            break
+    assert n_windows >= 2
+    if first_margin_problem is None:
+        assert got == ref
+        assert res.text == b"".join(E.Context.token_text(_Ctx(eng), t) for t in got if t < om.tok_eot).decode().strip()
+    else:
+        assert first_margin_problem < 2 * TOL_LOGIT[1]
+    eng.close()
