@@ -165,6 +165,9 @@ int ohw_engine_new(const char* model_path, const char* language, int translate, 
 int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32_t sample_rate,
                           char* text_buf, size_t text_cap, char* language_out, uint64_t* duration_ms,
                           ohw_audio_info* info);
+/* full text of the last transcribe (owned by the engine until the next call): a 2 h file can exceed any   */
+/* fixed text_buf; text_buf receives a truncated copy, this returns everything.                              */
+int ohw_engine_last_text(ohw_engine* e, const char** text, size_t* len);
 /* How audio longer than 30 s is windowed.  FIXED (default): host-side cuts every 30 s, windows batched
  * (BASELINE.json north_star).  SEEK: whisper.cpp's sequential loop as recalled (unpinned): the
  * next window starts at the last timestamp token of the previous one (seek += 2 * (ts - ts_begin) frames of

@@ -61,6 +61,7 @@ struct ohw_engine {
   int max_batch = 1;
   int window_mode = OHW_WINDOW_FIXED;
   std::vector<int32_t> last_tokens;
+  std::string last_text;
 };
 
 extern "C" {
@@ -311,6 +312,7 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
     const size_t b0 = text.find_first_not_of(" \t\r\n");
     const size_t b1 = text.find_last_not_of(" \t\r\n");
     text = b0 == std::string::npos ? std::string() : text.substr(b0, b1 - b0 + 1);
+    e->last_text = text;
     if (text_buf && text_cap > 0) {
       const size_t ncopy = std::min(text.size(), text_cap - 1);
       std::memcpy(text_buf, text.data(), ncopy);
@@ -325,6 +327,13 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
     if (duration_ms)
       *duration_ms = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
   });
+}
+
+int ohw_engine_last_text(ohw_engine* e, const char** text, size_t* len) {
+  if (!e || !text) return OHW_E_INVALID_ARG;
+  *text = e->last_text.c_str();
+  if (len) *len = e->last_text.size();
+  return OHW_OK;
 }
 
 int ohw_engine_set_window_mode(ohw_engine* e, int mode) {

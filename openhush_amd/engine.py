@@ -66,7 +66,7 @@ EXPORTS = [
     "ohw_default_sample_params", "ohw_sample_greedy_host", "ohw_greedy", "ohw_state_timings", "ohw_engine_new",
     "ohw_engine_transcribe", "ohw_engine_last_tokens", "ohw_engine_benchmark", "ohw_engine_free", "ohw_engine_state",
     "ohw_engine_ctx", "ohw_lang_id_to_code", "ohw_lang_code_to_id", "ohw_last_error", "ohw_abi_version", "ohw_state_fetch",
-    "ohw_dbg_gemm", "ohw_dbg_attention", "ohw_state_profile_begin", "ohw_state_profile_end", "ohw_ctx_weight_digest", "ohw_detect_language", "ohw_state_ctx", "ohw_engine_set_window_mode",
+    "ohw_dbg_gemm", "ohw_dbg_attention", "ohw_state_profile_begin", "ohw_state_profile_end", "ohw_ctx_weight_digest", "ohw_detect_language", "ohw_state_ctx", "ohw_engine_set_window_mode", "ohw_engine_last_text",
 ]
 
 
@@ -137,6 +137,7 @@ def lib():
         L.ohw_engine_transcribe.argtypes = [vp, fp, C.c_int64, C.c_uint32, C.c_char_p, C.c_size_t, C.c_char_p,
                                             C.POINTER(C.c_uint64), C.POINTER(AudioInfo)]
         L.ohw_engine_set_window_mode.argtypes = [vp, C.c_int]
+        L.ohw_engine_last_text.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
         L.ohw_engine_last_tokens.argtypes = [vp, C.POINTER(ip), C.POINTER(C.c_int)]
         L.ohw_engine_benchmark.argtypes = [vp, C.c_float, fp, fp, fp]
         L.ohw_engine_free.argtypes = [vp]
@@ -436,7 +437,7 @@ class WhisperEngine:
 
     def transcribe(self, audio: AudioBuffer) -> TranscriptionResult:
         s = np.ascontiguousarray(audio.samples, dtype=np.float32)
-        buf = C.create_string_buffer(1 << 16)
+        buf = C.create_string_buffer(256)
         lang = C.create_string_buffer(8)
         ms = C.c_uint64(0)
         info = AudioInfo()
@@ -444,7 +445,10 @@ class WhisperEngine:
         rc = lib().ohw_engine_transcribe(self.h, ptr, s.size, audio.sample_rate, buf, len(buf), lang, C.byref(ms), C.byref(info))
         if rc != 0:
             _raise(rc, info)
-        return TranscriptionResult(buf.value.decode("utf-8", "replace"), lang.value.decode(), int(ms.value))
+        full, n = C.c_char_p(), C.c_size_t(0)
+        _check(lib().ohw_engine_last_text(self.h, C.byref(full), C.byref(n)))   # the fixed buffer may have truncated
+        text = C.string_at(full, n.value).decode("utf-8", "replace") if n.value else ""
+        return TranscriptionResult(text, lang.value.decode(), int(ms.value))
 
     def set_window_mode(self, mode: int):
         """OHW_WINDOW_FIXED (0, default) or OHW_WINDOW_SEEK (1, whisper.cpp's timestamp-driven loop)"""
