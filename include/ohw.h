@@ -168,6 +168,12 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
 /* full text of the last transcribe (owned by the engine until the next call): a 2 h file can exceed any   */
 /* fixed text_buf; text_buf receives a truncated copy, this returns everything.                              */
 int ohw_engine_last_text(ohw_engine* e, const char** text, size_t* len);
+/* Decode quality of every window of the last transcribe, with whisper.cpp's fallback criteria (SURVEY.md A4.6,
+ * Appendix A: entropy_thold 2.4 over the last 32 tokens, logprob_thold -1.0).  whisper.cpp would re-decode a
+ * window that fails them at temperature 0.2, 0.4 ... with its own RNG stream; this engine stays greedy (T = 0,
+ * what `Greedy{best_of:1}` asks for first) and reports `would_fallback` instead of sampling. */
+typedef struct { int32_t n_tokens; float avg_logprob; float entropy; int32_t would_fallback; } ohw_window_quality;
+int ohw_engine_last_quality(ohw_engine* e, const ohw_window_quality** q, int* n_windows);
 /* How audio longer than 30 s is windowed.  FIXED (default): host-side cuts every 30 s, windows batched
  * (BASELINE.json north_star).  SEEK: whisper.cpp's sequential loop as recalled (unpinned): the
  * next window starts at the last timestamp token of the previous one (seek += 2 * (ts - ts_begin) frames of

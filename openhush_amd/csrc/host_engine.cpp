@@ -62,6 +62,7 @@ struct ohw_engine {
   int window_mode = OHW_WINDOW_FIXED;
   std::vector<int32_t> last_tokens;
   std::string last_text;
+  std::vector<ohw_window_quality> last_quality;
 };
 
 extern "C" {
@@ -261,8 +262,29 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
     if (sp.lang_id >= tk.n_langs) throw Error(OHW_E_TRANSCRIBE, "language is not supported by this model");
 
     e->last_tokens.clear();
+    e->last_quality.clear();
     std::string text;
     const int max_tok = e->ctx->hp.n_text_ctx;
+    // whisper.cpp's per-window acceptance test (as recalled): token-frequency entropy of the last 32 tokens
+    // and the average log-probability
+    auto quality = [&](const int32_t* t, int n, float sum_lp) {
+      ohw_window_quality q{};
+      q.n_tokens = n;
+      q.avg_logprob = n > 0 ? sum_lp / (float)n : 0.0f;
+      const int n32 = std::min(32, n);
+      double ent = 0.0;
+      for (int i = n - n32; i < n; ++i) {
+        bool first = true;
+        int cnt = 0;
+        for (int j = n - n32; j < n; ++j) {
+          if (t[j] == t[i]) { if (j < i) first = false; ++cnt; }
+        }
+        if (first && n32 > 0) { const double pr = (double)cnt / n32; ent -= pr * std::log(pr); }
+      }
+      q.entropy = (float)ent;
+      q.would_fallback = (n > 0 && (q.entropy < 2.4f || q.avg_logprob < -1.0f)) ? 1 : 0;
+      e->last_quality.push_back(q);
+    };
     auto append_text = [&](const int32_t* t, int n) {
       for (int i = 0; i < n; ++i) {
         e->last_tokens.push_back(t[i]);
@@ -277,6 +299,7 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
       // whisper.cpp's seek loop as recalled: sequential windows, advanced by the last timestamp
       std::vector<int32_t> toks((size_t)max_tok);
       int32_t ntok = 0;
+      float slp = 0.f;
       const int64_t seek_end = n / HOP;               // 10 ms frames
       int64_t seek = 0;
       while (seek + 100 < seek_end) {
@@ -284,13 +307,14 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
         const int32_t ns1 = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - off);
         int rc = ohw_mel(e->state, samples + off, CHUNK_SAMPLES, &ns1, 1, 0, OHW_MEL_ZERO_TAIL, nullptr);
         if (rc == OHW_OK) rc = ohw_encode(e->state, 1);
-        if (rc == OHW_OK) rc = ohw_greedy(e->state, &sp, 1, toks.data(), &ntok, max_tok, nullptr);
+        if (rc == OHW_OK) rc = ohw_greedy(e->state, &sp, 1, toks.data(), &ntok, max_tok, &slp);
         if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: " + g_last_error);
         int64_t seek_delta = 100 * 30;                // a full window when no timestamp was produced
         int result_len = ntok;
         for (int i = 0; i < ntok; ++i)
           if (toks[(size_t)i] > tk.timestamp_begin) { seek_delta = 2 * (int64_t)(toks[(size_t)i] - tk.timestamp_begin); result_len = i + 1; }
         if (seek_delta <= 0) seek_delta = 100 * 30;
+        quality(toks.data(), ntok, slp);
         append_text(toks.data(), result_len);
         seek += seek_delta;
       }
@@ -298,14 +322,18 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
       // host-side windowing: fixed 30 s cuts (BASELINE.json north_star)
       const int64_t n_win = (n + CHUNK_SAMPLES - 1) / CHUNK_SAMPLES;
       std::vector<int32_t> toks((size_t)e->max_batch * max_tok), ntok((size_t)e->max_batch), ns((size_t)e->max_batch);
+      std::vector<float> slp((size_t)e->max_batch);
       for (int64_t w0 = 0; w0 < n_win; w0 += e->max_batch) {
         const int B = (int)std::min<int64_t>(e->max_batch, n_win - w0);
         for (int b = 0; b < B; ++b) ns[(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + b) * CHUNK_SAMPLES);
         int rc = ohw_mel(e->state, samples + w0 * CHUNK_SAMPLES, CHUNK_SAMPLES, ns.data(), B, 0, OHW_MEL_ZERO_TAIL, nullptr);
         if (rc == OHW_OK) rc = ohw_encode(e->state, B);
-        if (rc == OHW_OK) rc = ohw_greedy(e->state, &sp, B, toks.data(), ntok.data(), max_tok, nullptr);
+        if (rc == OHW_OK) rc = ohw_greedy(e->state, &sp, B, toks.data(), ntok.data(), max_tok, slp.data());
         if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: " + g_last_error);   // reference :266-268
-        for (int b = 0; b < B; ++b) append_text(&toks[(size_t)b * max_tok], ntok[(size_t)b]);
+        for (int b = 0; b < B; ++b) {
+          quality(&toks[(size_t)b * max_tok], ntok[(size_t)b], slp[(size_t)b]);
+          append_text(&toks[(size_t)b * max_tok], ntok[(size_t)b]);
+        }
       }
     }
     // reference :282-283: trim
@@ -333,6 +361,13 @@ int ohw_engine_last_text(ohw_engine* e, const char** text, size_t* len) {
   if (!e || !text) return OHW_E_INVALID_ARG;
   *text = e->last_text.c_str();
   if (len) *len = e->last_text.size();
+  return OHW_OK;
+}
+
+int ohw_engine_last_quality(ohw_engine* e, const ohw_window_quality** q, int* n_windows) {
+  if (!e || !q || !n_windows) return OHW_E_INVALID_ARG;
+  *q = e->last_quality.data();
+  *n_windows = (int)e->last_quality.size();
   return OHW_OK;
 }
 

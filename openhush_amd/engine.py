@@ -53,6 +53,10 @@ class SampleParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("lang_id", "translate", "no_timestamps", "suppress_blank", "max_initial_ts", "n_max", "force_len")]
 
 
+class WindowQuality(C.Structure):
+    _fields_ = [("n_tokens", C.c_int32), ("avg_logprob", C.c_float), ("entropy", C.c_float), ("would_fallback", C.c_int32)]
+
+
 class Timings(C.Structure):
     _fields_ = [("mel_ms", C.c_float), ("encode_ms", C.c_float), ("decode_ms", C.c_float), ("total_ms", C.c_float), ("decode_steps", C.c_int32)]
 
@@ -66,7 +70,7 @@ EXPORTS = [
     "ohw_default_sample_params", "ohw_sample_greedy_host", "ohw_greedy", "ohw_state_timings", "ohw_engine_new",
     "ohw_engine_transcribe", "ohw_engine_last_tokens", "ohw_engine_benchmark", "ohw_engine_free", "ohw_engine_state",
     "ohw_engine_ctx", "ohw_lang_id_to_code", "ohw_lang_code_to_id", "ohw_last_error", "ohw_abi_version", "ohw_state_fetch",
-    "ohw_dbg_gemm", "ohw_dbg_attention", "ohw_state_profile_begin", "ohw_state_profile_end", "ohw_ctx_weight_digest", "ohw_detect_language", "ohw_state_ctx", "ohw_engine_set_window_mode", "ohw_engine_last_text",
+    "ohw_dbg_gemm", "ohw_dbg_attention", "ohw_state_profile_begin", "ohw_state_profile_end", "ohw_ctx_weight_digest", "ohw_detect_language", "ohw_state_ctx", "ohw_engine_set_window_mode", "ohw_engine_last_text", "ohw_engine_last_quality",
 ]
 
 
@@ -137,6 +141,7 @@ def lib():
         L.ohw_engine_transcribe.argtypes = [vp, fp, C.c_int64, C.c_uint32, C.c_char_p, C.c_size_t, C.c_char_p,
                                             C.POINTER(C.c_uint64), C.POINTER(AudioInfo)]
         L.ohw_engine_set_window_mode.argtypes = [vp, C.c_int]
+        L.ohw_engine_last_quality.argtypes = [vp, C.POINTER(C.POINTER(WindowQuality)), C.POINTER(C.c_int)]
         L.ohw_engine_last_text.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
         L.ohw_engine_last_tokens.argtypes = [vp, C.POINTER(ip), C.POINTER(C.c_int)]
         L.ohw_engine_benchmark.argtypes = [vp, C.c_float, fp, fp, fp]
@@ -449,6 +454,13 @@ class WhisperEngine:
         _check(lib().ohw_engine_last_text(self.h, C.byref(full), C.byref(n)))   # the fixed buffer may have truncated
         text = C.string_at(full, n.value).decode("utf-8", "replace") if n.value else ""
         return TranscriptionResult(text, lang.value.decode(), int(ms.value))
+
+    def last_quality(self):
+        """[(n_tokens, avg_logprob, entropy, would_fallback)] per window of the last transcribe"""
+        q = C.POINTER(WindowQuality)()
+        n = C.c_int(0)
+        _check(lib().ohw_engine_last_quality(self.h, C.byref(q), C.byref(n)))
+        return [(q[i].n_tokens, q[i].avg_logprob, q[i].entropy, bool(q[i].would_fallback)) for i in range(n.value)]
 
     def set_window_mode(self, mode: int):
         """OHW_WINDOW_FIXED (0, default) or OHW_WINDOW_SEEK (1, whisper.cpp's timestamp-driven loop)"""

@@ -219,6 +219,17 @@ def test_whisper_engine_mirror(E, oracle, models):
         assert agree >= 0.9 * n, (agree, n)
     text = b"".join(E.Context.token_text(_Ctx(eng), t) for t in toks if t < 50257)
     assert res.text == text.decode().strip()
+    # whisper.cpp's fallback criteria are reported per window (the engine itself stays greedy)
+    q = eng.last_quality()
+    assert len(q) == 3 and sum(n for n, *_ in q) == len(toks)
+    pos = 0
+    for n, avg_lp, ent, fb in q:
+        w = toks[pos:pos + n]; pos += n
+        last = w[-32:]
+        cnt = {t: last.count(t) for t in set(last)}
+        want = -sum(c / len(last) * np.log(c / len(last)) for c in cnt.values())
+        assert abs(ent - want) < 1e-4 and avg_lp <= 0.0
+        assert fb == (ent < 2.4 or avg_lp < -1.0)
     # validation errors surface as ValidationFailed with the reference's variant
     with pytest.raises(E.ValidationFailed) as ei:
         eng.transcribe(E.AudioBuffer(np.zeros(800, np.float32), 16000))
