@@ -1,0 +1,96 @@
+"""`openhush transcribe FILE` plumbing over the MI355X engine (BASELINE.json config #1).
+
+Mirrors the reference's one-shot CLI arm (reference src/main.rs:974-1077) and its WAV input contract
+(reference src/input/audio.rs:348-434, `load_wav_file`): integer samples / 2^(bits-1), channel average, pad
+with silence to 1.1 s; prints the same JSON fields as `--format json` (src/main.rs:1054-1066).
+Only 16 kHz input is accepted here: the reference resamples with the `rubato` sinc resampler, which belongs to
+the DSP front end (out of scope).
+
+    python -m openhush_amd.cli transcribe audio.wav --model-path /path/ggml-small.bin [--format json]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import struct
+import sys
+import time
+import wave
+
+import numpy as np
+
+SAMPLE_RATE = 16000
+WHISPER_MIN_DURATION_SECS = 1.1   # reference src/input/audio.rs:34
+
+
+def load_wav_file(path: str) -> np.ndarray:
+    """float32 mono 16 kHz samples, padded to 1.1 s like the reference's load_wav_file."""
+    with wave.open(path, "rb") as w:
+        rate, ch, width, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
+        raw = w.readframes(n)
+    if rate != SAMPLE_RATE:
+        raise ValueError(f"{path}: {rate} Hz input needs the resampling front end (only {SAMPLE_RATE} Hz is accepted here)")
+    if width == 1:      # 8-bit WAV is unsigned; hound yields i8 = u8 - 128
+        s = (np.frombuffer(raw, np.uint8).astype(np.int32) - 128).astype(np.float32) / np.float32(1 << 7)
+    elif width == 2:
+        s = np.frombuffer(raw, "<i2").astype(np.float32) / np.float32(1 << 15)
+    elif width == 3:
+        b = np.frombuffer(raw, np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        v = np.where(v >= 1 << 23, v - (1 << 24), v)
+        s = v.astype(np.float32) / np.float32(1 << 23)
+    elif width == 4:
+        s = np.frombuffer(raw, "<i4").astype(np.float32) / np.float32(2.0 ** 31)
+    else:
+        raise ValueError(f"{path}: unsupported sample width {width}")
+    if ch > 1:   # average the channels (reference :384-391)
+        s = (s[: len(s) // ch * ch].reshape(-1, ch).sum(axis=1, dtype=np.float32) / np.float32(ch)).astype(np.float32)
+    need = int(np.float32(SAMPLE_RATE) * np.float32(WHISPER_MIN_DURATION_SECS))
+    if len(s) / SAMPLE_RATE < WHISPER_MIN_DURATION_SECS:
+        s = np.concatenate([s, np.zeros(need - len(s), np.float32)])
+    return np.ascontiguousarray(s, dtype=np.float32)
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="openhush_amd.cli")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    t = sub.add_parser("transcribe")
+    t.add_argument("file")
+    t.add_argument("--model-path", required=True, help="ggml-*.bin model file")
+    t.add_argument("--model", default=None, help="name printed in the JSON (default: derived from the file name)")
+    t.add_argument("--language", default="auto")
+    t.add_argument("--translate", action="store_true")
+    t.add_argument("--format", default="text", choices=["text", "json"])
+    t.add_argument("--device", default="hip:0")
+    t.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    t.add_argument("--max-batch", type=int, default=8)
+    args = ap.parse_args(argv)
+
+    from . import engine as E
+    audio = E.AudioBuffer(load_wav_file(args.file), SAMPLE_RATE)
+    use_gpu = args.device.lower() != "cpu"                    # reference src/main.rs:1037
+    dev = int(args.device.split(":")[1]) if ":" in args.device else 0
+    t0 = time.perf_counter()
+    eng = E.WhisperEngine.new(args.model_path, args.language, args.translate, use_gpu, dev,
+                              E.OHW_DTYPE_BF16 if args.dtype == "bf16" else E.OHW_DTYPE_F16, args.max_batch)
+    print(f"Model loaded in {1e3 * (time.perf_counter() - t0):.0f}ms", file=sys.stderr)
+    t1 = time.perf_counter()
+    res = eng.transcribe(audio)
+    dt = time.perf_counter() - t1
+    rtf = dt / audio.duration_secs()
+    name = args.model or args.model_path.rsplit("/", 1)[-1].replace("ggml-", "").rsplit(".", 1)[0]
+    if args.format == "json":
+        print(json.dumps({"text": res.text, "language": res.language, "duration_ms": res.duration_ms,
+                          "audio_duration_secs": audio.duration_secs(), "transcription_time_ms": int(dt * 1e3),
+                          "real_time_factor": rtf, "model": name.lower()}, indent=2))
+    else:
+        print("\n--- Transcription ---")
+        print(res.text)
+        print("---")
+        print(f"\nTime: {dt * 1e3:.0f}ms (RTF: {rtf:.3f}x)")
+    eng.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

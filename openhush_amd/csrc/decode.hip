@@ -16,6 +16,24 @@ namespace ohw {
 // ------------------------------------------------------------------------------------------------
 // token + position embedding
 // ------------------------------------------------------------------------------------------------
+#ifdef OHW_TRACE
+// in-kernel timeline for tools/dec_trace.py (instrumented build only): first and last workgroup of each launch
+// append {100 MHz wall clock, kernel id, stage, which workgroup}
+__device__ unsigned long long ohw_trace_buf[1 << 18];
+__device__ unsigned ohw_trace_n;
+__device__ __forceinline__ void trace_mark(unsigned id, unsigned stage) {
+  const unsigned nb = gridDim.x * gridDim.y, bi = blockIdx.y * gridDim.x + blockIdx.x;
+  __builtin_amdgcn_sched_barrier(0);
+  if (threadIdx.x == 0 && (bi == 0 || bi == nb - 1 || bi == nb / 2)) {
+    const unsigned k = atomicAdd(&ohw_trace_n, 1u);
+    if (k < (1u << 18)) ohw_trace_buf[k] = ((unsigned long long)wall_clock64() << 16) | (id << 8) | (stage << 2) | (bi == 0 ? 0 : bi == nb - 1 ? 1 : 2);
+  }
+}
+#define TRACE(id, stage) trace_mark(id, stage)
+#else
+#define TRACE(id, stage)
+#endif
+
 template <typename T>
 __global__ void embed_kernel(const T* __restrict__ emb, const float* __restrict__ pos, const int32_t* __restrict__ tok,
                              const int32_t* __restrict__ n_past, float* __restrict__ x, int M, int n_new, int d) {
@@ -41,8 +59,9 @@ void launch_embed(const void* emb, const float* pos, const int32_t* tok, const i
 // share in flight at once: the kernel is latency-bound, not issue-bound), fixed-order LDS reduction
 // (bitwise reproducible, no atomics).
 // LN = true fuses the pre-LayerNorm of the fp32 residual stream into the prologue: the workgroup
-// normalises its 32 rows into LDS (16-bit, rows padded by 16 B against bank conflicts) and the MFMA
-// B operand is read from there.  Every workgroup redoes the 32-row LN (160 KB of L2 reads) - cheaper
+// normalises its 32 rows ((x - mean) * rstd; gamma and beta are folded into W and the bias at load, which
+// takes two dependent L2 round trips out of every such launch) into LDS (16-bit, rows padded by 16 B
+// against bank conflicts) and the MFMA B operand is read from there.  Every workgroup redoes the 32-row LN (160 KB of L2 reads) - cheaper
 // than one more dependent launch in a chain of 5 us kernels.
 // ------------------------------------------------------------------------------------------------
 constexpr int DG_THREADS = 512;
@@ -62,6 +81,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   const int kblocks = p.K / 32;
   const int ystride = p.K * 2 + 16;
   const int n_tiles = (p.N + 15) / 16;
+  TRACE(16 + EPI * 2 + (LN ? 1 : 0), 0);
 
   // epilogue coordinates are known up front: one output per thread and n-tile
   const int e_mt = tid >> 8, e_ll = (tid >> 2) & 63, e_reg = tid & 3;
@@ -136,28 +156,17 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
     const float rstd = rsqrtf(var / (float)p.K + 1e-5f);
-    // gamma / beta in groups of 5 float4 (L2 hits; all 5 of a group in flight)
+    // gamma / beta live in the weights and the bias (launch_fold_ln): only the normalisation is left here
 #pragma unroll
-    for (int i0 = 0; i0 < NV; i0 += 5) {
-      f32x4 g[5], bb[5];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const int c = ((i0 + j) * 16 + sub) * 4;
-        const int cc = c < p.K ? c : 0;
-        g[j] = *(const f32x4*)(p.ln_g + cc);
-        bb[j] = *(const f32x4*)(p.ln_b + cc);
-      }
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const int i = i0 + j;
-        const int c = (i * 16 + sub) * 4;
-        u32x2 w2;
-        w2.x = pack2<T>((v[i].x - mean) * rstd * g[j].x + bb[j].x, (v[i].y - mean) * rstd * g[j].y + bb[j].y);
-        w2.y = pack2<T>((v[i].z - mean) * rstd * g[j].z + bb[j].z, (v[i].w - mean) * rstd * g[j].w + bb[j].w);
-        if (c < p.K) *(u32x2*)(ylds + row * ystride + c * 2) = w2;
-      }
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 16 + sub) * 4;
+      u32x2 w2;
+      w2.x = pack2<T>((v[i].x - mean) * rstd, (v[i].y - mean) * rstd);
+      w2.y = pack2<T>((v[i].z - mean) * rstd, (v[i].w - mean) * rstd);
+      if (c < p.K) *(u32x2*)(ylds + row * ystride + c * 2) = w2;
     }
     __syncthreads();
+    TRACE(16 + EPI * 2 + 1, 1);
   }
 
   const T* __restrict__ x = (const T*)p.x;
@@ -257,6 +266,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
     for (; kb < kblocks; kb += DG_WAVES) run(std::integral_constant<int, 1>{}, kb);
   }
 
+  TRACE(16 + EPI * 2 + (LN ? 1 : 0), 2);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     part[((wave * NT + t) * 2 + 0) * 64 + lane] = acc[t][0];
@@ -297,6 +307,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
       if (m % p.n_new == p.n_new - 1) ((float*)p.out)[(int64_t)(m / p.n_new) * p.ld_out + n] = v;
     }
   }
+  TRACE(16 + EPI * 2 + (LN ? 1 : 0), 3);
 }
 
 template <typename T, int EPI, bool LN, int NT>
@@ -319,8 +330,8 @@ static void dec_gemm_pick(const DecGemmParams& p, hipStream_t s) {
 template <typename T>
 void launch_dec_gemm(const DecGemmParams& p, int epilogue, hipStream_t s) {
   if (p.K % 32 != 0) throw Error(OHW_E_INVALID_ARG, "dec_gemm: K must be a multiple of 32");
-  const bool ln = p.ln_g != nullptr;
-  if (ln && (p.K % 64 != 0 || p.K > DG_LN_MAXK || !p.ln_b)) throw Error(OHW_E_INVALID_ARG, "dec_gemm: fused LayerNorm needs K <= 1280, K % 64 == 0");
+  const bool ln = p.ln != 0;
+  if (ln && (p.K % 64 != 0 || p.K > DG_LN_MAXK)) throw Error(OHW_E_INVALID_ARG, "dec_gemm: fused LayerNorm needs K <= 1280, K % 64 == 0");
   switch (epilogue) {
     case DEPI_QKV: if (ln) dec_gemm_pick<T, DEPI_QKV, true>(p, s); else dec_gemm_pick<T, DEPI_QKV, false>(p, s); break;
     case DEPI_BIAS_T: if (ln) dec_gemm_pick<T, DEPI_BIAS_T, true>(p, s); else dec_gemm_pick<T, DEPI_BIAS_T, false>(p, s); break;
@@ -348,6 +359,7 @@ __global__ __launch_bounds__(64) void self_attn_kernel(const T* __restrict__ q, 
   const int h = blockIdx.x, m = blockIdx.y;
   const int b = m / n_new, i = m % n_new;
   const int d = n_head * 64;
+  TRACE(2, 0);
   int n_keys = n_past[b] + i + 1;
   if (n_keys > n_ctx) n_keys = n_ctx;
   const T* kb = kc + (((int64_t)b * n_head + h) * n_ctx << 6);
@@ -387,6 +399,7 @@ __global__ __launch_bounds__(64) void self_attn_kernel(const T* __restrict__ q, 
     o = o * alpha + acc;
   }
   out[(int64_t)m * d + h * 64 + lane] = (T)(o / l_run);
+  TRACE(2, 3);
 }
 template <typename T>
 void launch_self_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* n_past, void* out, int M, int n_new,
@@ -417,6 +430,7 @@ __global__ __launch_bounds__(XA_THREADS) void cross_attn_kernel(const T* __restr
   const int d = n_head * 64;
   const int part = lane & 7, slot = lane >> 3;
   const float sc = 0.125f * 1.44269504088896340736f;
+  TRACE(3, 0);
   float qv[8];
   {
     const vec8_t<T> qq = *(const vec8_t<T>*)(q + (int64_t)m * d + h * 64 + part * 8);
@@ -461,6 +475,7 @@ __global__ __launch_bounds__(XA_THREADS) void cross_attn_kernel(const T* __restr
       for (int e = 0; e < 8; ++e) acc[e] = acc[e] * alpha + pe * (float)vf[u][e];
     }
   }
+  TRACE(3, 2);
   // merge the 8 slots of this wave (lanes with equal `part`): xor 8, 16, 32
 #pragma unroll
   for (int o = 8; o <= 32; o <<= 1) {
@@ -493,6 +508,7 @@ __global__ __launch_bounds__(XA_THREADS) void cross_attn_kernel(const T* __restr
     }
     out[(int64_t)m * d + h * 64 + tid] = (T)(o / l);
   }
+  TRACE(3, 3);
 }
 template <typename T>
 void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out, int M, int n_new, int n_head, int t_len, hipStream_t s) {
@@ -627,3 +643,18 @@ INST(f16_t)
 #undef INST
 
 }  // namespace ohw
+
+#ifdef OHW_TRACE
+// instrumented build only: copy the timeline out and reset it (returns the number of records)
+extern "C" int ohw_dbg_trace_read(unsigned long long* out, int cap) {
+  unsigned n = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(ohw::ohw_trace_n), sizeof(n)) != hipSuccess) return -1;
+  if (n > (1u << 18)) n = 1u << 18;
+  if ((int)n > cap) n = cap;
+  if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(ohw::ohw_trace_buf), (size_t)n * 8) != hipSuccess) return -1;
+  const unsigned zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(ohw::ohw_trace_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+  return (int)n;
+}
+#endif

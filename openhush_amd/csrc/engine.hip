@@ -237,7 +237,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
   auto gemm = [&](const void* x, const LayerNormW* ln, const DevBuf& w, const DevBuf& bias, void* out, int N, int K, int epi, int64_t ld) {
     DecGemmParams p{};
     p.x = x; p.w = w.p; p.bias = bias.p ? bias.as<float>() : nullptr; p.out = out;
-    if (ln) { p.ln_g = ln->g.as<float>(); p.ln_b = ln->b.as<float>(); }
+    p.ln = ln ? 1 : 0;
     p.M = M; p.N = N; p.K = K; p.n_new = n_new; p.ld_out = ld; p.n_past = n_past;
     p.d_model = d; p.n_head = H; p.n_ctx = C;
     const int cls = epi == DEPI_BIAS_T ? OHW_PROF_DEC_GEMM_XQ : epi == DEPI_BIAS_GELU_T ? OHW_PROF_DEC_GEMM_FC1
@@ -251,7 +251,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
     T* vc = kc + kv_layer;
     {  // LN1 + fused QKV projection; K/V go straight into the cache at each window's position
       DecGemmParams p{};
-      p.x = st->dx.p; p.ln_g = w.ln1.g.as<float>(); p.ln_b = w.ln1.b.as<float>();
+      p.x = st->dx.p; p.ln = 1;
       p.w = w.wqkv.p; p.bias = w.bqkv.as<float>(); p.out = st->dq.p;
       p.M = M; p.N = 3 * d; p.K = d; p.n_new = n_new; p.ld_out = d;
       p.k_cache = kc; p.v_cache = vc; p.n_past = n_past; p.d_model = d; p.n_head = H; p.n_ctx = C;

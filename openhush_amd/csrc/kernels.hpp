@@ -14,6 +14,9 @@ template <typename T> void launch_convert_rows(const float* src, void* dst, int6
 template <typename T> void launch_repack_conv(const float* src, void* dst, int64_t d_out, int64_t c_in, int64_t c_pad, hipStream_t s);
 // decoder linear [N][K] f32 -> MFMA-fragment tiles T [Npad/16][K/32][64][8], rows >= N zero
 template <typename T> void launch_repack_tiled(const float* src, void* dst, int64_t N, int64_t n_pad, int64_t K, hipStream_t s);
+// fold a pre-LayerNorm's affine part into the linear layer that follows it (in place, f32 [N][K]):
+//   bias[n] += sum_k beta[k] * W[n][k];  W[n][k] *= gamma[k]      so that  LN(x) W^T + b == ((x - mean) rstd) W'^T + b'
+void launch_fold_ln(float* w, float* bias, const float* gamma, const float* beta, int64_t N, int64_t K, hipStream_t s);
 
 // ---- front end (mel.hip) -----------------------------------------------------------------------
 struct MelParams {
@@ -43,8 +46,8 @@ enum DecEpilogue {
   DEPI_LOGITS = 4      // logits f32 [batch][ld_logits], only rows m with (m % n_new) == n_new - 1
 };
 struct DecGemmParams {
-  const void* x;       // T [M][K]; with ln_g != nullptr: f32 [M][K] residual stream, LayerNorm fused
-  const float* ln_g; const float* ln_b;
+  const void* x;       // T [M][K]; with ln != 0: f32 [M][K] residual stream, (x - mean) * rstd fused into the prologue
+  int32_t ln;          //   (gamma / beta of that LayerNorm are folded into w / bias at load: launch_fold_ln)
   const void* w;       // tiled T [Npad/16][K/32][64][8]
   const float* bias;   // [N] or nullptr
   void* out;           // see DecEpilogue

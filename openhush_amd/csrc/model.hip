@@ -77,6 +77,37 @@ struct Placer {
   int placed = 0;
   explicit Placer(ohw_ctx* ctx, hipStream_t st) : c(ctx), s(st) {}
 
+  // Decoder pre-LayerNorms are folded into the linear layer they feed (launch_fold_ln): the decode GEMMs then
+  // only normalise.  Tensors arrive in file order, so the f32 copies of the five affected matrices of a layer
+  // wait here until that layer's LayerNorms and biases are in; then: fold, repack, free.
+  enum { F_WQ, F_WK, F_WV, F_WXQ, F_W1, F_BQ, F_BV, F_BXQ, F_B1, F_LN1G, F_LN1B, F_LNXG, F_LNXB, F_LN2G, F_LN2B, F_COUNT };
+  struct PendingLayer { DevBuf w[5]; unsigned seen = 0; };
+  std::vector<PendingLayer> pending;
+
+  void stash(int li, int slot, const float* src, int64_t n) {
+    if (pending.empty()) pending.resize(c->dec.size());
+    pending[li].w[slot].alloc((size_t)n * 4);
+    HIP_CHECK(hipMemcpyAsync(pending[li].w[slot].p, src, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  }
+  void arrived(int li, int what) {
+    if (pending.empty()) pending.resize(c->dec.size());
+    PendingLayer& pl = pending[li];
+    pl.seen |= 1u << what;
+    if (pl.seen != (1u << F_COUNT) - 1) return;
+    DecLayerW& l = c->dec[li];
+    const int64_t dt = c->hp.n_text_state;
+    for (int q = 0; q < 3; ++q) {
+      launch_fold_ln((float*)pl.w[q].p, l.bqkv.as<float>() + q * dt, l.ln1.g.as<float>(), l.ln1.b.as<float>(), dt, dt, s);
+      launch_repack_tiled<T>((float*)pl.w[q].p, (T*)l.wqkv.p + q * dt * dt, dt, dt, dt, s);
+    }
+    launch_fold_ln((float*)pl.w[F_WXQ].p, l.bxq.as<float>(), l.lnx.g.as<float>(), l.lnx.b.as<float>(), dt, dt, s);
+    launch_repack_tiled<T>((float*)pl.w[F_WXQ].p, l.wxq.p, dt, dt, dt, s);
+    launch_fold_ln((float*)pl.w[F_W1].p, l.b1.as<float>(), l.ln2.g.as<float>(), l.ln2.b.as<float>(), 4 * dt, dt, s);
+    launch_repack_tiled<T>((float*)pl.w[F_W1].p, l.w1.p, 4 * dt, 4 * dt, dt, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (auto& b : pl.w) b.release();
+  }
+
   static void f32_copy(DevBuf& dst, const float* src, int64_t n, hipStream_t s) {
     HIP_CHECK(hipMemcpyAsync(dst.p, src, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
   }
@@ -193,28 +224,28 @@ struct Placer {
       if (li < 0 || li >= hp.n_text_layer) throw Error(OHW_E_LOAD_FAILED, "layer index out of range: " + name);
       DecLayerW& l = c->dec[li];
       const std::string lf = leaf;
-      if (lf == "attn_ln.weight") { vec(l.ln1.g, dt); return true; }
-      if (lf == "attn_ln.bias") { vec(l.ln1.b, dt); return true; }
-      if (lf == "attn.query.weight") { tiled(l.wqkv, dt, dt, 0); return true; }
-      if (lf == "attn.query.bias") { vec(l.bqkv, dt, 0); return true; }
-      if (lf == "attn.key.weight") { tiled(l.wqkv, dt, dt, dt); return true; }
-      if (lf == "attn.value.weight") { tiled(l.wqkv, dt, dt, 2 * dt); return true; }
-      if (lf == "attn.value.bias") { vec(l.bqkv, dt, 2 * dt); return true; }
+      if (lf == "attn_ln.weight") { vec(l.ln1.g, dt); arrived(li, F_LN1G); return true; }
+      if (lf == "attn_ln.bias") { vec(l.ln1.b, dt); arrived(li, F_LN1B); return true; }
+      if (lf == "attn.query.weight") { expect(dt * dt); stash(li, F_WQ, src, n); arrived(li, F_WQ); return true; }
+      if (lf == "attn.query.bias") { vec(l.bqkv, dt, 0); arrived(li, F_BQ); return true; }
+      if (lf == "attn.key.weight") { expect(dt * dt); stash(li, F_WK, src, n); arrived(li, F_WK); return true; }
+      if (lf == "attn.value.weight") { expect(dt * dt); stash(li, F_WV, src, n); arrived(li, F_WV); return true; }
+      if (lf == "attn.value.bias") { vec(l.bqkv, dt, 2 * dt); arrived(li, F_BV); return true; }
       if (lf == "attn.out.weight") { tiled(l.wo, dt, dt); return true; }
       if (lf == "attn.out.bias") { vec(l.bo, dt); return true; }
-      if (lf == "cross_attn_ln.weight") { vec(l.lnx.g, dt); return true; }
-      if (lf == "cross_attn_ln.bias") { vec(l.lnx.b, dt); return true; }
-      if (lf == "cross_attn.query.weight") { tiled(l.wxq, dt, dt); return true; }
-      if (lf == "cross_attn.query.bias") { vec(l.bxq, dt); return true; }
+      if (lf == "cross_attn_ln.weight") { vec(l.lnx.g, dt); arrived(li, F_LNXG); return true; }
+      if (lf == "cross_attn_ln.bias") { vec(l.lnx.b, dt); arrived(li, F_LNXB); return true; }
+      if (lf == "cross_attn.query.weight") { expect(dt * dt); stash(li, F_WXQ, src, n); arrived(li, F_WXQ); return true; }
+      if (lf == "cross_attn.query.bias") { vec(l.bxq, dt); arrived(li, F_BXQ); return true; }
       if (lf == "cross_attn.key.weight") { plain(c->xkv_w, dt, d, (int64_t)(2 * li) * dt); return true; }
       if (lf == "cross_attn.value.weight") { plain(c->xkv_w, dt, d, (int64_t)(2 * li + 1) * dt); return true; }
       if (lf == "cross_attn.value.bias") { vec(c->xkv_b, dt, (int64_t)(2 * li + 1) * dt); return true; }
       if (lf == "cross_attn.out.weight") { tiled(l.wxo, dt, dt); return true; }
       if (lf == "cross_attn.out.bias") { vec(l.bxo, dt); return true; }
-      if (lf == "mlp_ln.weight") { vec(l.ln2.g, dt); return true; }
-      if (lf == "mlp_ln.bias") { vec(l.ln2.b, dt); return true; }
-      if (lf == "mlp.0.weight") { tiled(l.w1, 4 * dt, dt); return true; }
-      if (lf == "mlp.0.bias") { vec(l.b1, 4 * dt); return true; }
+      if (lf == "mlp_ln.weight") { vec(l.ln2.g, dt); arrived(li, F_LN2G); return true; }
+      if (lf == "mlp_ln.bias") { vec(l.ln2.b, dt); arrived(li, F_LN2B); return true; }
+      if (lf == "mlp.0.weight") { expect(4 * dt * dt); stash(li, F_W1, src, n); arrived(li, F_W1); return true; }
+      if (lf == "mlp.0.bias") { vec(l.b1, 4 * dt); arrived(li, F_B1); return true; }
       if (lf == "mlp.2.weight") { tiled(l.w2, dt, 4 * dt); return true; }
       if (lf == "mlp.2.bias") { vec(l.b2, dt); return true; }
     }

@@ -89,6 +89,23 @@ void launch_repack_tiled(const float* src, void* dst, int64_t N, int64_t n_pad, 
   HIP_CHECK(hipGetLastError());
 }
 
+__global__ __launch_bounds__(256) void fold_ln_kernel(float* __restrict__ w, float* __restrict__ bias, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int64_t K) {
+  __shared__ float red[4];
+  float* row = w + (int64_t)blockIdx.x * K;
+  float acc = 0.f;
+  for (int64_t k = threadIdx.x; k < K; k += 256) acc += beta[k] * row[k];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) bias[blockIdx.x] += (red[0] + red[1]) + (red[2] + red[3]);
+  for (int64_t k = threadIdx.x; k < K; k += 256) row[k] *= gamma[k];
+}
+void launch_fold_ln(float* w, float* bias, const float* gamma, const float* beta, int64_t N, int64_t K, hipStream_t s) {
+  hipLaunchKernelGGL(fold_ln_kernel, dim3((unsigned)N), dim3(256), 0, s, w, bias, gamma, beta, K);
+  HIP_CHECK(hipGetLastError());
+}
+
 #define INST(T) \
   template void launch_convert_rows<T>(const float*, void*, int64_t, int64_t, int64_t, hipStream_t); \
   template void launch_repack_conv<T>(const float*, void*, int64_t, int64_t, int64_t, hipStream_t);  \

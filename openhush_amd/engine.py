@@ -20,7 +20,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libohw.so")
+LIB_PATH = os.environ.get("OHW_LIB") or os.path.join(_HERE, "libohw.so")   # OHW_LIB: instrumented builds for tools/
 
 CHUNK_SAMPLES = 480000
 CHUNK_FRAMES = 3000
