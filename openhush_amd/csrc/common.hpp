@@ -96,6 +96,14 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// Activation operand of the decoder's skinny GEMMs (decode.hip): 16-row tiles in MFMA B-fragment order,
+// T [ceil(M/16)][K/32][64 lanes][8], lane = (m % 16) + 16 * ((k % 32) / 8).  A wave then loads one k-block of a
+// tile as 1 KiB contiguous (8 whole cache lines, each read once) instead of 16 half-used lines 2*K bytes apart -
+// with row-major activations those loads, not the weight stream, set the time of every such GEMM.
+__device__ __forceinline__ int64_t act_tiled_offset(int m, int k, int K) {
+  return ((((int64_t)(m >> 4) * (K >> 5) + (k >> 5)) * 64 + (m & 15) + 16 * ((k & 31) >> 3)) << 3) + (k & 7);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

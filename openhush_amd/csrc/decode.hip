@@ -22,7 +22,7 @@ namespace ohw {
 __device__ unsigned long long ohw_trace_buf[1 << 18];
 __device__ unsigned ohw_trace_n;
 __device__ __forceinline__ void trace_mark(unsigned id, unsigned stage) {
-  const unsigned nb = gridDim.x * gridDim.y, bi = blockIdx.y * gridDim.x + blockIdx.x;
+  const unsigned nb = gridDim.x * gridDim.y * gridDim.z, bi = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   __builtin_amdgcn_sched_barrier(0);
   if (threadIdx.x == 0 && (bi == 0 || bi == nb - 1 || bi == nb / 2)) {
     const unsigned k = atomicAdd(&ohw_trace_n, 1u);
@@ -86,8 +86,11 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   // epilogue coordinates are known up front: one output per thread and n-tile
   const int e_mt = tid >> 8, e_ll = (tid >> 2) & 63, e_reg = tid & 3;
   const int e_m = m0 + e_mt * 16 + (e_ll & 15);
+  // split-K (RESID only, gridDim.z slices): this workgroup owns k-blocks [k_lo, k_hi)
+  const int ksplit = gridDim.z;
+  const int k_lo = (int)((int64_t)kblocks * blockIdx.z / ksplit), k_hi = (int)((int64_t)kblocks * (blockIdx.z + 1) / ksplit);
   float resid_old[NT];
-  if constexpr (EPI == DEPI_BIAS_RESID) {
+  if (EPI == DEPI_BIAS_RESID && ksplit == 1) {
     // issue the read of the residual now: its latency hides under the weight stream
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -170,11 +173,9 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   }
 
   const T* __restrict__ x = (const T*)p.x;
-  int r0 = m0 + (lane & 15), r1 = m0 + 16 + (lane & 15);
-  if (r0 > p.M - 1) r0 = p.M - 1;
-  if (r1 > p.M - 1) r1 = p.M - 1;
-  const T* x0 = LN ? nullptr : x + (int64_t)r0 * p.K + (lane >> 4) * 8;
-  const T* x1 = LN ? nullptr : x + (int64_t)r1 * p.K + (lane >> 4) * 8;
+  // activation tiles: k-block kk of the 16-row tile mt is the 1 KiB at ((mt * kblocks + kk) * 64 + lane) * 8 elements
+  const T* x0 = LN ? nullptr : x + ((int64_t)(m0 >> 4) * kblocks * 64 + lane) * 8;
+  const T* x1 = LN ? nullptr : x0 + (int64_t)kblocks * 512;
   const unsigned char* y0 = ylds + (lane & 15) * ystride + (lane >> 4) * 16;
   const unsigned char* y1 = y0 + 16 * ystride;
   f32x4 acc[NT][2];
@@ -195,8 +196,8 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
         a[u] = *(const vec8*)(y0 + kk * 64);
         b[u] = *(const vec8*)(y1 + kk * 64);
       } else {
-        a[u] = *(const vec8*)(x0 + kk * 32);
-        b[u] = *(const vec8*)(x1 + kk * 32);
+        a[u] = *(const vec8*)(x0 + (int64_t)kk * 512);
+        b[u] = *(const vec8*)(x1 + (int64_t)kk * 512);
       }
     }
     // keep every load above issued before the first MFMA (the scheduler otherwise sinks loads next to
@@ -231,11 +232,11 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
         acc[t][1] = Ops::mfma16(wpre[t][u], b[u], acc[t][1]);
       }
   } else {
-    int kb = wave;
+    int kb = k_lo + wave;
     // long K (mlp.2; one CU pulls its 160 KiB at ~17 GB/s, which is why this is the slowest of the small GEMMs: a
     // 4-way split-K variant with an ordered combine kernel was measured at the same 15 us and dropped): every weight block of the wave's share is requested at once (20 KiB per wave, one HBM
     // round trip); the activation fragments are L2 hits and are fetched five at a time right before use
-    for (; kb + DG_WAVES * 19 < kblocks; kb += DG_WAVES * 20) {
+    for (; kb + DG_WAVES * 19 < k_hi; kb += DG_WAVES * 20) {
       constexpr int UW = 20;
       vec8 w[NT][UW];
 #pragma unroll
@@ -248,8 +249,8 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
           const int kk = kb + DG_WAVES * (g + u);
-          a[u] = *(const vec8*)(x0 + kk * 32);
-          b[u] = *(const vec8*)(x1 + kk * 32);
+          a[u] = *(const vec8*)(x0 + (int64_t)kk * 512);
+          b[u] = *(const vec8*)(x1 + (int64_t)kk * 512);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -261,9 +262,9 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
           }
       }
     }
-    for (; kb + DG_WAVES * 9 < kblocks; kb += DG_WAVES * 10) run(std::integral_constant<int, 10>{}, kb);
-    for (; kb + DG_WAVES * 4 < kblocks; kb += DG_WAVES * 5) run(std::integral_constant<int, 5>{}, kb);
-    for (; kb < kblocks; kb += DG_WAVES) run(std::integral_constant<int, 1>{}, kb);
+    for (; kb + DG_WAVES * 9 < k_hi; kb += DG_WAVES * 10) run(std::integral_constant<int, 10>{}, kb);
+    for (; kb + DG_WAVES * 4 < k_hi; kb += DG_WAVES * 5) run(std::integral_constant<int, 5>{}, kb);
+    for (; kb < k_hi; kb += DG_WAVES) run(std::integral_constant<int, 1>{}, kb);
   }
 
   TRACE(16 + EPI * 2 + (LN ? 1 : 0), 2);
@@ -273,6 +274,49 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
     part[((wave * NT + t) * 2 + 1) * 64 + lane] = acc[t][1];
   }
   __syncthreads();
+  if constexpr (EPI == DEPI_BIAS_RESID && NT == 1) {
+    if (ksplit > 1) {
+      // Cross-workgroup split-K without spinning and without float atomics: every slice writes its 32 x 16 partial
+      // tile through to memory (sc1 stores, drained), takes a ticket, and the slice that draws the last ticket sums
+      // all slices in slice order (bitwise reproducible whatever the arrival order) and applies the epilogue.
+      // Hand-off form: cdna_hip_programming.md Guideline 16 (sc1 payload + drain + barrier + one agent-scope add;
+      // the last adder reads with sc1 loads behind a workgroup barrier).
+      __shared__ unsigned s_ticket;
+      const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.slab, 0, p.slab_bytes, 0x00020000);
+      const int l2 = tid & 63, mt2 = (tid >> 6) & 1;
+      if (tid < 128) {
+        f32x4 sum = part[(0 * 2 + mt2) * 64 + l2];
+#pragma unroll
+        for (int w = 1; w < DG_WAVES; ++w) sum += part[(w * 2 + mt2) * 64 + l2];
+        union { f32x4 f; u32x4 u; } cv; cv.f = sum;
+        __builtin_amdgcn_raw_buffer_store_b128(cv.u, rs, (int)(((tile * ksplit + blockIdx.z) * 128 + tid) * 16), 0, 16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) s_ticket = __hip_atomic_fetch_add(p.ticket + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (s_ticket != (unsigned)ksplit - 1) return;
+      if (tid == 0) __hip_atomic_store(p.ticket + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+      if (tid < 128) {
+        f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < ksplit; ++sl) {
+          union { f32x4 f; u32x4 u; } cv;
+          cv.u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((tile * ksplit + sl) * 128 + tid) * 16), 0, 16);
+          tot += cv.f;
+        }
+        const int m = m0 + mt2 * 16 + (l2 & 15), n0 = nt0 * 16 + 4 * (l2 >> 4);
+        if (m < p.M) {
+          float* xo = (float*)p.out + (int64_t)m * p.ld_out + n0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n0 + r < p.N) xo[r] = xo[r] + (tot[r] + (p.bias ? p.bias[n0 + r] : 0.f));
+        }
+      }
+      TRACE(16 + EPI * 2, 3);
+      return;
+    }
+  }
   // per n-tile: 2 m-tiles x 64 lanes x 4 regs = 512 outputs, one per thread
   // D layout: n = 4*(lane'>>4) + reg, m = mt*16 + (lane' & 15)
   const float* pp = (const float*)part;
@@ -300,7 +344,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
     } else if constexpr (EPI == DEPI_BIAS_T) {
       ((T*)p.out)[(int64_t)m * p.ld_out + n] = (T)v;
     } else if constexpr (EPI == DEPI_BIAS_GELU_T) {
-      ((T*)p.out)[(int64_t)m * p.ld_out + n] = (T)gelu_erf(v);
+      ((T*)p.out)[act_tiled_offset(m, n, p.N)] = (T)gelu_erf(v);
     } else if constexpr (EPI == DEPI_BIAS_RESID) {
       ((float*)p.out)[(int64_t)m * p.ld_out + n] = resid_old[t] + v;
     } else if constexpr (EPI == DEPI_LOGITS) {
@@ -313,7 +357,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
 template <typename T, int EPI, bool LN, int NT>
 static void dec_gemm_launch(const DecGemmParams& p, hipStream_t s) {
   const int n_tiles = (p.N + 15) / 16;
-  dim3 grid((n_tiles + NT - 1) / NT, (p.M + 31) / 32);
+  dim3 grid((n_tiles + NT - 1) / NT, (p.M + 31) / 32, p.ksplit > 1 ? p.ksplit : 1);
   const size_t smem = (size_t)DG_WAVES * NT * 2 * 64 * 16 + (LN ? (size_t)32 * (p.K * 2 + 16) : 0);
   if (LN) ensure_dynamic_lds((const void*)dec_gemm_kernel<T, EPI, LN, NT>, 160 * 1024);
   hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, LN, NT>), grid, dim3(DG_THREADS), smem, s, p);
@@ -331,6 +375,11 @@ template <typename T>
 void launch_dec_gemm(const DecGemmParams& p, int epilogue, hipStream_t s) {
   if (p.K % 32 != 0) throw Error(OHW_E_INVALID_ARG, "dec_gemm: K must be a multiple of 32");
   const bool ln = p.ln != 0;
+  if (p.ksplit > 1) {
+    const int64_t tiles = (int64_t)((p.N + 15) / 16) * ((p.M + 31) / 32);
+    if (epilogue != DEPI_BIAS_RESID || !p.slab || !p.ticket || tiles * p.ksplit * 2048 > p.slab_bytes || p.ksplit > p.K / 32)
+      throw Error(OHW_E_INVALID_ARG, "dec_gemm: split-K needs the RESID epilogue and a slab of tiles * ksplit * 2 KiB");
+  }
   if (ln && (p.K % 64 != 0 || p.K > DG_LN_MAXK)) throw Error(OHW_E_INVALID_ARG, "dec_gemm: fused LayerNorm needs K <= 1280, K % 64 == 0");
   switch (epilogue) {
     case DEPI_QKV: if (ln) dec_gemm_pick<T, DEPI_QKV, true>(p, s); else dec_gemm_pick<T, DEPI_QKV, false>(p, s); break;
@@ -398,7 +447,7 @@ __global__ __launch_bounds__(64) void self_attn_kernel(const T* __restrict__ q, 
     for (int j = 0; j < 64; ++j) acc += ps[j] * (float)vr[j];   // masked keys carry p = 0
     o = o * alpha + acc;
   }
-  out[(int64_t)m * d + h * 64 + lane] = (T)(o / l_run);
+  out[act_tiled_offset(m, h * 64 + lane, d)] = (T)(o / l_run);
   TRACE(2, 3);
 }
 template <typename T>
@@ -506,7 +555,7 @@ __global__ __launch_bounds__(XA_THREADS) void cross_attn_kernel(const T* __restr
       l += red_l[w] * a;
       o += red_o[w][tid] * a;
     }
-    out[(int64_t)m * d + h * 64 + tid] = (T)(o / l);
+    out[act_tiled_offset(m, h * 64 + tid, d)] = (T)(o / l);
   }
   TRACE(3, 3);
 }

@@ -44,6 +44,20 @@ static int guard(F&& f) {
 
 using namespace ohw;
 
+constexpr int DEC_KSPLIT_MAX = 8;   // most K-slices per output tile of a decoder RESID GEMM
+static int env_int(const char* name, int dflt, int lo, int hi) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  const int v = atoi(e);
+  return v < lo ? lo : v > hi ? hi : v;
+}
+// K-slices per output tile of the decoder's RESID GEMMs, read when a state is created (1 = no split, the default:
+// with activation tiles mlp.2 takes 7.8 us unsplit, 7.6 us over 2 slices and 9.4 us over 4 - the hand-off costs
+// about 3.5 us - so the split path is kept as a tuning knob for other shapes, exercised by the GPU tests)
+static int dec_ksplit_long() { return env_int("OHW_DEC_KSPLIT_LONG", 1, 1, DEC_KSPLIT_MAX); }
+static int dec_ksplit_short() { return env_int("OHW_DEC_KSPLIT_SHORT", 1, 1, DEC_KSPLIT_MAX); }
+
+
 struct ohw_state {
   ohw_ctx* ctx = nullptr;
   int max_batch = 0;
@@ -61,6 +75,8 @@ struct ohw_state {
   DevBuf xkv;      // T [2L][B][H][1500][64]
   DevBuf self_kv;  // T [L][2][B][H][n_text_ctx][64]
   DevBuf dx, dy, dq, da, df, logits;
+  DevBuf ks_slab, ks_ticket;   // split-K partial tiles and arrival tickets of the decoder's RESID GEMMs
+  int ksplit_long = 1, ksplit_short = 1;
   DevBuf step_tok, n_past, tokens, n_cur, next_tok, done, n_done, sum_lp;
   int m_max = 0;
   int64_t logits_ld = 0;
@@ -136,10 +152,20 @@ void state_alloc(ohw_state* st) {
   st->self_kv.alloc((size_t)L * 2 * B * H * hp.n_text_ctx * 64 * 2, true);
   st->m_max = (int)B * 8;
   st->dx.alloc((size_t)st->m_max * dt * 4);
-  st->dy.alloc((size_t)st->m_max * dt * 2);
+  // dy / da / df are read as 16-row activation tiles by 32-row workgroups: whole tiles, zeroed once (rows past M are
+  // multiplied but never stored)
+  const size_t m_tiles = ((size_t)st->m_max + 31) / 32 * 32;
+  st->dy.alloc(m_tiles * dt * 2, true);
   st->dq.alloc((size_t)st->m_max * dt * 2);
-  st->da.alloc((size_t)st->m_max * dt * 2);
-  st->df.alloc((size_t)st->m_max * 4 * dt * 2);
+  st->da.alloc(m_tiles * dt * 2, true);
+  st->df.alloc(m_tiles * 4 * dt * 2, true);
+  {
+    const size_t tiles = (size_t)((dt + 15) / 16) * ((st->m_max + 31) / 32);
+    st->ks_slab.alloc(tiles * DEC_KSPLIT_MAX * 2048);
+    st->ks_ticket.alloc(tiles * 4, true);
+    st->ksplit_long = dec_ksplit_long();
+    st->ksplit_short = dec_ksplit_short();
+  }
   st->logits_ld = c->v_pad;
   st->logits.alloc((size_t)B * st->logits_ld * 4);
   st->max_tokens = hp.n_text_ctx;
@@ -238,12 +264,21 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
     DecGemmParams p{};
     p.x = x; p.w = w.p; p.bias = bias.p ? bias.as<float>() : nullptr; p.out = out;
     p.ln = ln ? 1 : 0;
+    if (epi == DEPI_BIAS_RESID) {
+      const int ks = K >= 2 * d ? st->ksplit_long : st->ksplit_short;
+      if (ks > 1 && ks <= K / 32) {
+        p.ksplit = ks; p.slab = st->ks_slab.as<float>(); p.slab_bytes = (int32_t)st->ks_slab.bytes; p.ticket = st->ks_ticket.as<unsigned>();
+      }
+    }
     p.M = M; p.N = N; p.K = K; p.n_new = n_new; p.ld_out = ld; p.n_past = n_past;
     p.d_model = d; p.n_head = H; p.n_ctx = C;
     const int cls = epi == DEPI_BIAS_T ? OHW_PROF_DEC_GEMM_XQ : epi == DEPI_BIAS_GELU_T ? OHW_PROF_DEC_GEMM_FC1
                   : epi == DEPI_LOGITS ? OHW_PROF_DEC_GEMM_LOGITS : OHW_PROF_DEC_GEMM;
     ProfScope ps(st, cls, 2.0 * ((double)((N + 15) / 16 * 16) * K) * ((M + 31) / 32));
     launch_dec_gemm<T>(p, epi, s);
+#ifdef OHW_EXP_DOUBLE
+    launch_dec_gemm<T>(p, epi, s);   // timing experiment only (instrumented build): the same launch again, everything warm
+#endif
   };
   for (int l = 0; l < L; ++l) {
     const DecLayerW& w = c->dec[l];
@@ -270,7 +305,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
     gemm(st->dx.p, &w.ln2, w.w1, w.b1, st->df.p, 4 * d, d, DEPI_BIAS_GELU_T, 4 * d);
     gemm(st->df.p, nullptr, w.w2, w.b2, st->dx.p, d, 4 * d, DEPI_BIAS_RESID, d);
   }
-  launch_layernorm<T>(st->dx.as<float>(), c->dec_ln.g.as<float>(), c->dec_ln.b.as<float>(), st->dy.p, M, d, s);
+  launch_layernorm<T>(st->dx.as<float>(), c->dec_ln.g.as<float>(), c->dec_ln.b.as<float>(), st->dy.p, M, d, s, true);
   DevBuf none;
   gemm(st->dy.p, nullptr, c->emb, none, st->logits.p, hp.n_vocab, d, DEPI_LOGITS, st->logits_ld);
 }

@@ -34,19 +34,21 @@ struct MelParams {
 template <typename T> void launch_mel(const MelParams& p, hipStream_t s);
 
 // ---- normalisation (misc.hip) --------------------------------------------------------------------
-template <typename T> void launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int64_t rows, int d, hipStream_t s);
+// tiled = true writes y in the decoder GEMMs' activation order (act_tiled_offset, common.hpp) instead of row-major
+template <typename T> void launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int64_t rows, int d, hipStream_t s,
+                                            bool tiled = false);
 template <typename T> void launch_to_f32(const void* src, float* dst, int64_t n, hipStream_t s);
 
 // ---- decoder step (decode.hip) ---------------------------------------------------------------------
 enum DecEpilogue {
   DEPI_QKV = 0,        // n < d: q T [M][d]; d <= n < 2d: self-K cache; 2d <= n: self-V cache (+bias)
   DEPI_BIAS_T = 1,     // out T [M][N]
-  DEPI_BIAS_GELU_T = 2,
+  DEPI_BIAS_GELU_T = 2, // out T in activation-tile order (it feeds mlp.2)
   DEPI_BIAS_RESID = 3, // x f32 [M][N] += v + bias
   DEPI_LOGITS = 4      // logits f32 [batch][ld_logits], only rows m with (m % n_new) == n_new - 1
 };
 struct DecGemmParams {
-  const void* x;       // T [M][K]; with ln != 0: f32 [M][K] residual stream, (x - mean) * rstd fused into the prologue
+  const void* x;       // T activation tiles [ceil(M/16)][K/32][64][8] (act_tiled_offset); with ln != 0: f32 [M][K] residual stream, (x - mean) * rstd fused into the prologue
   int32_t ln;          //   (gamma / beta of that LayerNorm are folded into w / bias at load: launch_fold_ln)
   const void* w;       // tiled T [Npad/16][K/32][64][8]
   const float* bias;   // [N] or nullptr
@@ -57,16 +59,21 @@ struct DecGemmParams {
   const int32_t* n_past;            // device [B]
   int32_t d_model, n_head, n_ctx;
   int64_t ld_out;
+  // DEPI_BIAS_RESID with ksplit > 1: K is split over ksplit workgroups per output tile (see decode.hip)
+  int32_t ksplit;                   // 0 / 1 = off
+  int32_t slab_bytes;
+  float* slab;                      // f32 [tiles][ksplit][512]
+  unsigned* ticket;                 // [tiles], zero between launches (the kernel re-arms it)
 };
 template <typename T> void launch_dec_gemm(const DecGemmParams& p, int epilogue, hipStream_t s);
 
 // x f32 [M][d] = token_embedding[tok[m]] + pos_emb[n_past[m / n_new] + m % n_new]
 template <typename T> void launch_embed(const void* emb_tiled, const float* pos, const int32_t* tok, const int32_t* n_past,
                                         float* x, int M, int n_new, int d, hipStream_t s);
-// causal self-attention of the new tokens against the cache.  q T [M][d] -> out T [M][d]
+// causal self-attention of the new tokens against the cache.  q T [M][d] -> out T, activation-tile order
 template <typename T> void launch_self_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* n_past,
                                             void* out, int M, int n_new, int n_head, int n_ctx, hipStream_t s);
-// cross-attention: q T [M][d]; cross K/V head-major T [B][H][t_len][64] of this layer -> out T [M][d]
+// cross-attention: q T [M][d]; cross K/V head-major T [B][H][t_len][64] of this layer -> out T, activation-tile order
 template <typename T> void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out, int M, int n_new,
                                              int n_head, int t_len, hipStream_t s);
 

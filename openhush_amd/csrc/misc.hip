@@ -6,7 +6,7 @@ namespace ohw {
 // one wave per row; two-pass mean / variance in registers (same arithmetic order class as the oracle)
 template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, T* __restrict__ y, int64_t rows, int d) {
+                                                        const float* __restrict__ beta, T* __restrict__ y, int64_t rows, int d, int tiled) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -49,19 +49,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     u32x2 w;
     w.x = pack2<T>((v[i].x - mean) * rstd * g[i].x + bb[i].x, (v[i].y - mean) * rstd * g[i].y + bb[i].y);
     w.y = pack2<T>((v[i].z - mean) * rstd * g[i].z + bb[i].z, (v[i].w - mean) * rstd * g[i].w + bb[i].w);
-    if (c < d) *(u32x2*)(yr + c) = w;
+    if (c < d) *(u32x2*)(tiled ? y + act_tiled_offset((int)row, c, d) : yr + c) = w;
   }
 }
 
 template <typename T>
-void launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int64_t rows, int d, hipStream_t s) {
+void launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int64_t rows, int d, hipStream_t s, bool tiled) {
   if (rows <= 0) return;
+  if (tiled && d % 32 != 0) throw Error(OHW_E_INVALID_ARG, "layernorm: the tiled output needs d % 32 == 0");
+  const int tl = tiled ? 1 : 0;
   if (d % 4 != 0 || d > 2048) throw Error(OHW_E_INVALID_ARG, "layernorm: d must be a multiple of 4 and <= 2048");
   const unsigned blocks = (unsigned)((rows + 3) / 4);
-  if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(blocks), dim3(256), 0, s, x, gamma, beta, (T*)y, rows, d);
-  else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<T, 4>), dim3(blocks), dim3(256), 0, s, x, gamma, beta, (T*)y, rows, d);
-  else if (d <= 1280) hipLaunchKernelGGL((layernorm_kernel<T, 5>), dim3(blocks), dim3(256), 0, s, x, gamma, beta, (T*)y, rows, d);
-  else hipLaunchKernelGGL((layernorm_kernel<T, 8>), dim3(blocks), dim3(256), 0, s, x, gamma, beta, (T*)y, rows, d);
+  if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(blocks), dim3(256), 0, s, x, gamma, beta, (T*)y, rows, d, tl);
+  else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<T, 4>), dim3(blocks), dim3(256), 0, s, x, gamma, beta, (T*)y, rows, d, tl);
+  else if (d <= 1280) hipLaunchKernelGGL((layernorm_kernel<T, 5>), dim3(blocks), dim3(256), 0, s, x, gamma, beta, (T*)y, rows, d, tl);
+  else hipLaunchKernelGGL((layernorm_kernel<T, 8>), dim3(blocks), dim3(256), 0, s, x, gamma, beta, (T*)y, rows, d, tl);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -77,7 +79,7 @@ void launch_to_f32(const void* src, float* dst, int64_t n, hipStream_t s) {
 }
 
 #define INST(T) \
-  template void launch_layernorm<T>(const float*, const float*, const float*, void*, int64_t, int, hipStream_t); \
+  template void launch_layernorm<T>(const float*, const float*, const float*, void*, int64_t, int, hipStream_t, bool); \
   template void launch_to_f32<T>(const void*, float*, int64_t, hipStream_t);
 INST(bf16_t)
 INST(f16_t)

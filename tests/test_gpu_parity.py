@@ -183,6 +183,30 @@ def test_force_len_and_batch_invariance(E, models):
         assert t1[0] == t3[b], b   # a window's result does not depend on its batch neighbours
 
 
+def test_split_k_residual_gemms_match_unsplit(E, models, monkeypatch):
+    """The decoder's RESID GEMMs over K-slices (sc1 slabs + arrival ticket, summed in slice order by the last arriver)
+    give the logits of the unsplit path up to fp32 re-association, run after run."""
+    _, _, _, ctxs = models
+    ctx = ctxs[0]
+    pcm, ns = _pcm_batch()
+    toks = np.tile(np.array([ctx.tok.sot, ctx.tok.sot + 1, ctx.tok.transcribe, 60, 70, 80], np.int32), (3, 1))
+
+    def logits(long, short):
+        monkeypatch.setenv("OHW_DEC_KSPLIT_LONG", str(long))
+        monkeypatch.setenv("OHW_DEC_KSPLIT_SHORT", str(short))
+        st = E.State(ctx, 3)          # the knobs are read when a state is created
+        st.mel(pcm, ns, E.OHW_MEL_ZERO_TAIL, want=False)
+        st.encode(3)
+        out = [st.decode(toks[:, :4], [0, 0, 0]), st.decode(toks[:, 4:5], [4, 4, 4]), st.decode(toks[:, 5:6], [5, 5, 5])]
+        return np.concatenate([o.reshape(3, -1) for o in out], axis=1)
+
+    base = logits(1, 1)
+    for long, short in ((4, 1), (2, 3), (8, 2)):
+        a, b = logits(long, short), logits(long, short)
+        assert np.array_equal(a, b), (long, short)                       # no arrival-order dependence
+        assert np.max(np.abs(a - base)) < 2e-3 * max(1.0, float(np.max(np.abs(base)))), (long, short)
+
+
 def test_synthetic_context_equals_file_context(E, models):
     preset, _, _, ctxs = models
     syn = E.Context.synthetic(synth.PRESETS[preset].as_list(), 1234, 0, 0)

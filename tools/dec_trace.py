@@ -16,7 +16,7 @@ import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
-os.environ["OHW_LIB"] = os.path.join(R, "openhush_amd", "libohw_trace.so")
+os.environ.setdefault("OHW_LIB", os.path.join(R, "openhush_amd", "libohw_trace.so"))
 
 import ctypes as C  # noqa: E402
 
@@ -62,15 +62,16 @@ def main():
     rec = sorted((int(v) >> 16, (int(v) >> 8) & 255, (int(v) >> 2) & 63, int(v) & 3) for v in buf[:n])
     # launches in order of their earliest entry mark: group consecutive records of one kernel id
     launches = []
+    cur_of = {}
     for t, kid, stage, which in rec:
-        if stage == 0 and (not launches or launches[-1]["id"] != kid or launches[-1]["done"]):
-            launches.append({"id": kid, "t": collections.defaultdict(list), "done": False})
-        cur = next(l for l in reversed(launches) if l["id"] == kid)
-        cur["t"][stage].append(t)
-        if stage == 3 and len(cur["t"][3]) == len(cur["t"][0]) and len(cur["t"][0]) >= 3:
-            cur["done"] = True
-    # one token step = from a QKV gemm of layer 0 (the launch after a LOGITS gemm) to the next LOGITS
-    idx = [i for i, l in enumerate(launches) if kname(l["id"]).startswith("gemm<LOGITS")]
+        if stage == 0 and which == 0:          # workgroup 0 enters: a new launch of this kernel
+            cur_of[kid] = {"id": kid, "t": collections.defaultdict(list)}
+            launches.append(cur_of[kid])
+        if kid in cur_of:
+            cur_of[kid]["t"][stage].append(t)
+    # one token step = the launches between two LOGITS gemms
+    names = [kname(l["id"]) for l in launches]
+    idx = [i for i, k in enumerate(names) if k.startswith("gemm<LOGITS") and (i + 1 == len(names) or not names[i + 1].startswith("gemm<LOGITS"))]
     if len(idx) < 3:
         print("too few steps recorded", len(launches))
         return
