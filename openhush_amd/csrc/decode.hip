@@ -236,6 +236,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
     // long K (mlp.2; one CU pulls its 160 KiB at ~17 GB/s, which is why this is the slowest of the small GEMMs: a
     // 4-way split-K variant with an ordered combine kernel was measured at the same 15 us and dropped): every weight block of the wave's share is requested at once (20 KiB per wave, one HBM
     // round trip); the activation fragments are L2 hits and are fetched five at a time right before use
+    if constexpr (NT == 1)
     for (; kb + DG_WAVES * 19 < k_hi; kb += DG_WAVES * 20) {
       constexpr int UW = 20;
       vec8 w[NT][UW];
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
           }
       }
     }
+    if constexpr (NT == 1)
     for (; kb + DG_WAVES * 9 < k_hi; kb += DG_WAVES * 10) run(std::integral_constant<int, 10>{}, kb);
     for (; kb + DG_WAVES * 4 < k_hi; kb += DG_WAVES * 5) run(std::integral_constant<int, 5>{}, kb);
     for (; kb < k_hi; kb += DG_WAVES) run(std::integral_constant<int, 1>{}, kb);
@@ -367,7 +369,8 @@ template <typename T, int EPI, bool LN>
 static void dec_gemm_pick(const DecGemmParams& p, hipStream_t s) {
   // with the LayerNorm image in LDS one workgroup fills a CU: keep the grid within one wave of 256 CUs
   const int n_tiles = (p.N + 15) / 16;
-  if (LN && n_tiles > 256) dec_gemm_launch<T, EPI, LN, 2>(p, s);
+  static const int logits_nt = getenv("OHW_LOGITS_NT") ? atoi(getenv("OHW_LOGITS_NT")) : 2;
+  if ((LN && n_tiles > 256) || (EPI == DEPI_LOGITS && logits_nt == 2)) dec_gemm_launch<T, EPI, LN, 2>(p, s);
   else dec_gemm_launch<T, EPI, LN, 1>(p, s);
 }
 
@@ -570,7 +573,7 @@ void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out,
 // logits filter + greedy arg-max on the device: restates oracle ref_process_logits / ref_greedy
 // (whisper.cpp defaults).  One workgroup per window.
 // ------------------------------------------------------------------------------------------------
-constexpr int SP_THREADS = 1024;
+constexpr int SP_THREADS = 512;
 
 struct SampState {
   int is_initial, last_ts, penult_ts, last_seen, suppress_eot;
@@ -610,9 +613,12 @@ __device__ __forceinline__ void samp_merge(SampAcc& a, const SampAcc& b) {
 
 // ONE pass over the logits row: masked online log-sum-exp (all / timestamps) and the best text and
 // best timestamp candidates; the timestamp-mass rule then only chooses between the two candidates.
+// The scan is VALU-bound (the rule test per token), so a window's row is cut into SAMPLER_SPLIT slices on as many
+// CUs; each slice publishes its partial state (agent-scope stores, drained) and takes a ticket, and the workgroup that
+// draws the last ticket merges the partials in slice order and applies the decision (no spinning, reproducible).
 __global__ __launch_bounds__(SP_THREADS) void sampler_kernel(SamplerParams p) {
   __shared__ SampAcc sh[SP_THREADS / 64];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   if (p.done[b]) return;
   const int np_now = p.n_past[b] + p.advance;
   const float* lg = p.logits + (int64_t)b * p.ld;
@@ -625,21 +631,36 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_kernel(SamplerParams p) {
   st.last_seen = -1;
   for (int i = n_cur - 1; i >= 0; --i) if (toks[i] >= p.ts_begin) { st.last_seen = toks[i]; break; }
   st.suppress_eot = p.force_len > 0 && n_cur < p.force_len;
-  const int V = p.n_vocab;
+  const int per = (p.n_vocab + SAMPLER_SPLIT - 1) / SAMPLER_SPLIT;
+  const int lo = part * per, V = lo + per < p.n_vocab ? lo + per : p.n_vocab;
   SampAcc a;
   a.m = -INFINITY; a.s_all = 0.f; a.s_ts = 0.f; a.tv = -INFINITY; a.ti = 0x7fffffff; a.zv = -INFINITY; a.zi = 0x7fffffff;
-  for (int i = tid; i < V; i += SP_THREADS) {
-    const float v = lg[i];                     // unconditional load; masked below
-    if (!sp_allowed(p, st, i)) continue;
-    if (v > a.m) {
-      const float f = a.m == -INFINITY ? 0.f : expf(a.m - v);
-      a.s_all *= f; a.s_ts *= f; a.m = v;
+  // batches of SP_BATCH loads per thread, all in flight before the first is used
+  constexpr int SP_BATCH = 13;
+  TRACE(4, 0);
+  for (int i0 = lo + tid; i0 < V; i0 += SP_THREADS * SP_BATCH) {
+    float vv[SP_BATCH];
+#pragma unroll
+    for (int u = 0; u < SP_BATCH; ++u) {
+      const int i = i0 + u * SP_THREADS;
+      vv[u] = lg[i < V ? i : V - 1];           // unconditional load (clamped address); masked below
     }
-    const float e = expf(v - a.m);
-    a.s_all += e;
-    if (i >= p.ts_begin) { a.s_ts += e; if (v > a.zv) { a.zv = v; a.zi = i; } }
-    else if (v > a.tv) { a.tv = v; a.ti = i; }
+#pragma unroll
+    for (int u = 0; u < SP_BATCH; ++u) {
+      const int i = i0 + u * SP_THREADS;
+      const float v = vv[u];
+      if (i >= V || !sp_allowed(p, st, i)) continue;
+      if (v > a.m) {
+        const float f = a.m == -INFINITY ? 0.f : expf(a.m - v);
+        a.s_all *= f; a.s_ts *= f; a.m = v;
+      }
+      const float e = expf(v - a.m);
+      a.s_all += e;
+      if (i >= p.ts_begin) { a.s_ts += e; if (v > a.zv) { a.zv = v; a.zi = i; } }
+      else if (v > a.tv) { a.tv = v; a.ti = i; }
+    }
   }
+  TRACE(4, 2);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     SampAcc bb;
@@ -651,34 +672,59 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_kernel(SamplerParams p) {
   __syncthreads();
   if (tid == 0) {
     for (int w = 1; w < SP_THREADS / 64; ++w) samp_merge(a, sh[w]);
-    const float lse = a.m + logf(a.s_all);
-    bool force_ts = false;
-    if (!p.no_timestamps && a.s_ts > 0.f) {
-      const float ts_lp = a.m + logf(a.s_ts) - lse;
-      const float text_lp = a.tv - lse;
-      force_ts = ts_lp > text_lp;
+    // publish this slice, take a ticket; only the last arriver goes on (one thread does all of it, in program order)
+    unsigned* slot = (unsigned*)p.partials + ((int64_t)b * SAMPLER_SPLIT + part) * 8;
+    const unsigned words[7] = {__float_as_uint(a.m), __float_as_uint(a.s_all), __float_as_uint(a.s_ts), __float_as_uint(a.tv), (unsigned)a.ti,
+                               __float_as_uint(a.zv), (unsigned)a.zi};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) __hip_atomic_store(slot + k, words[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(p.tickets + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == SAMPLER_SPLIT - 1) {
+      __hip_atomic_store(p.tickets + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned* all = (const unsigned*)p.partials + (int64_t)b * SAMPLER_SPLIT * 8;
+      unsigned w8[SAMPLER_SPLIT][7];
+#pragma unroll
+      for (int q = 0; q < SAMPLER_SPLIT; ++q)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) w8[q][k] = __hip_atomic_load(all + q * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int q = 0; q < SAMPLER_SPLIT; ++q) {
+        SampAcc c;
+        c.m = __uint_as_float(w8[q][0]); c.s_all = __uint_as_float(w8[q][1]); c.s_ts = __uint_as_float(w8[q][2]);
+        c.tv = __uint_as_float(w8[q][3]); c.ti = (int)w8[q][4]; c.zv = __uint_as_float(w8[q][5]); c.zi = (int)w8[q][6];
+        if (q == 0) a = c; else samp_merge(a, c);
+      }
+      const float lse = a.m + logf(a.s_all);
+      bool force_ts = false;
+      if (!p.no_timestamps && a.s_ts > 0.f) {
+        const float ts_lp = a.m + logf(a.s_ts) - lse;
+        const float text_lp = a.tv - lse;
+        force_ts = ts_lp > text_lp;
+      }
+      // arg-max over what is left; text indices are below timestamp indices, so ties go to text
+      float bv; int bi;
+      if (force_ts || a.zv > a.tv) { bv = a.zv; bi = a.zi; } else { bv = a.tv; bi = a.ti; }
+      const int n_max = p.force_len > 0 ? p.force_len : p.n_max;
+      bool finished = false;
+      if (bi == p.eot) {
+        finished = true;
+      } else {
+        toks[n_cur] = bi;
+        p.n_cur[b] = n_cur + 1;
+        p.sum_logprob[b] += bv - lse;
+        p.next_tok[b] = bi;
+        if (p.advance) p.n_past[b] = np_now;
+        const int np = np_now;
+        if (n_cur + 1 >= n_max || n_cur + 1 >= p.max_tokens || np + 1 >= p.n_text_ctx) finished = true;
+      }
+      if (finished) { p.done[b] = 1; atomicAdd(p.n_done, 1); }
     }
-    // arg-max over what is left; text indices are below timestamp indices, so ties go to text
-    float bv; int bi;
-    if (force_ts || a.zv > a.tv) { bv = a.zv; bi = a.zi; } else { bv = a.tv; bi = a.ti; }
-    const int n_max = p.force_len > 0 ? p.force_len : p.n_max;
-    bool finished = false;
-    if (bi == p.eot) {
-      finished = true;
-    } else {
-      toks[n_cur] = bi;
-      p.n_cur[b] = n_cur + 1;
-      p.sum_logprob[b] += bv - lse;
-      p.next_tok[b] = bi;
-      if (p.advance) p.n_past[b] = np_now;
-      const int np = np_now;
-      if (n_cur + 1 >= n_max || n_cur + 1 >= p.max_tokens || np + 1 >= p.n_text_ctx) finished = true;
-    }
-    if (finished) { p.done[b] = 1; atomicAdd(p.n_done, 1); }
   }
+  TRACE(4, 3);
 }
 void launch_sampler(const SamplerParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(sampler_kernel, dim3(p.batch), dim3(SP_THREADS), 0, s, p);
+  hipLaunchKernelGGL(sampler_kernel, dim3(SAMPLER_SPLIT, p.batch), dim3(SP_THREADS), 0, s, p);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -77,6 +77,7 @@ struct ohw_state {
   DevBuf dx, dy, dq, da, df, logits;
   DevBuf ks_slab, ks_ticket;   // split-K partial tiles and arrival tickets of the decoder's RESID GEMMs
   int ksplit_long = 1, ksplit_short = 1;
+  DevBuf samp_part, samp_ticket;   // sampler: per-slice partial states and arrival tickets
   DevBuf step_tok, n_past, tokens, n_cur, next_tok, done, n_done, sum_lp;
   int m_max = 0;
   int64_t logits_ld = 0;
@@ -163,6 +164,8 @@ void state_alloc(ohw_state* st) {
     const size_t tiles = (size_t)((dt + 15) / 16) * ((st->m_max + 31) / 32);
     st->ks_slab.alloc(tiles * DEC_KSPLIT_MAX * 2048);
     st->ks_ticket.alloc(tiles * 4, true);
+    st->samp_part.alloc((size_t)B * SAMPLER_SPLIT * 8 * 4, true);
+    st->samp_ticket.alloc((size_t)B * 4, true);
     st->ksplit_long = dec_ksplit_long();
     st->ksplit_short = dec_ksplit_short();
   }
@@ -317,6 +320,7 @@ void fill_sampler(const ohw_state* st, const ohw_sample_params* sp, int B, Sampl
   p->tokens = st->tokens.as<int32_t>(); p->n_cur = st->n_cur.as<int32_t>(); p->n_past = st->n_past.as<int32_t>();
   p->next_tok = st->next_tok.as<int32_t>(); p->done = st->done.as<int32_t>(); p->n_done = st->n_done.as<int32_t>();
   p->sum_logprob = st->sum_lp.as<float>();
+  p->partials = st->samp_part.as<float>(); p->tickets = st->samp_ticket.as<unsigned>();
   p->batch = B; p->max_tokens = st->max_tokens; p->n_vocab = c->hp.n_vocab;
   p->eot = c->tok.eot; p->sot = c->tok.sot; p->translate = c->tok.translate; p->transcribe = c->tok.transcribe;
   p->solm = c->tok.solm; p->prev = c->tok.prev; p->nosp = c->tok.nosp; p->no_ts = c->tok.no_timestamps;

@@ -92,7 +92,11 @@ struct SamplerParams {
   int32_t eot, sot, translate, transcribe, solm, prev, nosp, no_ts, ts_begin, blank, n_langs;
   int32_t suppress_blank, no_timestamps, max_initial_ts, n_max, force_len, n_text_ctx;
   int32_t advance;       // 1: n_past[b] += 1 first (a single-token step ran since the last call)
+  // the row is scanned by SAMPLER_SPLIT workgroups per window; the one that draws the last ticket merges the partials
+  float* partials;       // [batch][SAMPLER_SPLIT][8]
+  unsigned* tickets;     // [batch], zero between launches (re-armed by the kernel)
 };
+constexpr int SAMPLER_SPLIT = 8;
 void launch_sampler(const SamplerParams& p, hipStream_t s);
 
 }  // namespace ohw

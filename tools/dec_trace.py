@@ -25,7 +25,7 @@ import torch  # noqa: E402
 
 from openhush_amd import engine as E, synth  # noqa: E402
 
-NAMES = {2: "self_attn", 3: "cross_attn"}
+NAMES = {2: "self_attn", 3: "cross_attn", 4: "sampler"}
 EPI = {0: "QKV", 1: "BIAS_T", 2: "GELU", 3: "RESID", 4: "LOGITS"}
 
 
