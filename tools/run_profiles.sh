@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round profile set, run on the GPU box:   gpurun --timeout 1200 -- bash tools/run_profiles.sh
+# then here:                                cp gpurun_out/profiles_out/* profiles/
+# One kernel-trace pass of the full bench workload, then PMC passes (one counter set per pass, kernel trace only,
+# reduced token count: counters serialise the dispatches) as MI355X_MICROARCH.md's HBM / rocprofv3 section prescribes.
+set -eo pipefail
+cd "${GRAFT_REPO_ROOT:-$PWD}"
+export TMPDIR=/tmp
+O=gpurun_out
+rm -rf $O/prof_final $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_GRBM_GUI_ACTIVE $O/pmc_sq
+echo "[profiles] bench bf16"; python3 bench.py --steps 3 --warmup 1 > $O/bench_final.json 2> $O/bench_final.err
+echo "[profiles] bench f16";  python3 bench.py --steps 3 --warmup 1 --dtype f16 --no-cpu-baseline > $O/bench_f16.json 2> $O/bench_f16.err
+echo "[profiles] kernel trace"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_final -- python3 bench.py --steps 3 --warmup 0 --no-cpu-baseline > $O/prof_final.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
+  echo "[profiles] pmc $c"
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 bench.py --steps 1 --warmup 0 --tokens 6 --no-cpu-baseline > $O/pmc_$c.log 2>&1
+done
+echo "[profiles] pmc sq"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 1 --warmup 0 --tokens 6 --no-cpu-baseline > $O/pmc_sq.log 2>&1
+# the per-dispatch CSVs (> 100 MB) cannot travel back (64 MiB limit): summarise here, keep only the summaries
+TAG=${1:-r01}
+python3 tools/summarize_profiles.py $TAG $O/profiles_out > $O/profiles_out.log 2>&1
+cp $O/bench_final.json $O/profiles_out/${TAG}_bench_large-v3_b32.json
+cp $O/bench_f16.json $O/profiles_out/${TAG}_bench_large-v3_b32_f16.json
+rm -rf $O/prof_final $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_GRBM_GUI_ACTIVE $O/pmc_sq
+ls -la $O/profiles_out
+echo "[profiles] done"

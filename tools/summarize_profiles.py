@@ -15,16 +15,19 @@ import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
-os.makedirs(f"{R}/profiles", exist_ok=True)
+# on the GPU box the raw per-dispatch CSVs (> 100 MB) cannot travel back: tools/run_profiles.sh summarises there, into
+# gpurun_out/profiles_out/, and the files are then copied to profiles/ here
+P = sys.argv[2] if len(sys.argv) > 2 else f"{R}/profiles"
+os.makedirs(P, exist_ok=True)
 
 ks = glob.glob(f"{R}/gpurun_out/prof_final/*/*_kernel_stats.csv")[0]
-shutil.copy(ks, f"{R}/profiles/{TAG}_bench_large-v3_b32_kernel_stats.csv")
+shutil.copy(ks, f"{P}/{TAG}_bench_large-v3_b32_kernel_stats.csv")
 tr = glob.glob(f"{R}/gpurun_out/prof_final/*/*_kernel_trace.csv")[0]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(tr)):
     agg[(r["Kernel_Name"], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 tot = sum(sum(v) for v in agg.values())
-with open(f"{R}/profiles/{TAG}_bench_large-v3_b32_kernel_by_grid.csv", "w") as f:
+with open(f"{P}/{TAG}_bench_large-v3_b32_kernel_by_grid.csv", "w") as f:
     f.write("kernel,workgroups,calls,total_ms,avg_us,median_us,share_pct\n")
     for (k, g), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         v.sort()
@@ -67,6 +70,6 @@ for key in sorted(fe, key=lambda k: -sum(x[0] for x in fe[k]["FETCH_SIZE"])):
                     "fetch_size_kb_raw": sum(f) / n, "write_size_kb": sum(w) / len(w),
                     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                             "(gfx950 reports half of a wide coalesced read); single-token steps only (640 workgroups)"}
-open(f"{R}/profiles/{TAG}_pmc_by_kernel.csv", "w").write("\n".join(lines) + "\n")
-json.dump(out, open(f"{R}/profiles/{TAG}_pmc_summary.json", "w"), indent=1)
+open(f"{P}/{TAG}_pmc_by_kernel.csv", "w").write("\n".join(lines) + "\n")
+json.dump(out, open(f"{P}/{TAG}_pmc_summary.json", "w"), indent=1)
 print("\n".join(l[:200] for l in lines[:12]))
