@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--profile-class", type=int, default=0, help="0 = pick the class with the largest total time")
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many concurrent states/streams")
+    ap.add_argument("--pipeline", type=int, default=96,
+                    help="N > 0 (default 96): two batches in flight - mel/encoder/cross-K/V of batch i+1 on N compute units beside the "
+                         "decoder of batch i on the rest; 0: one batch after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=0, help="decode tokens in the CPU sample (0 = same as --tokens)")
     ap.add_argument("--cpu-windows", type=int, default=3, help="30 s windows in the CPU sample")
@@ -125,16 +128,68 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        toks = step()
+    def run_steps(n):
+        toks = None
+        for _ in range(n):
+            toks = step()
+        return toks
+
+    pipe = None
+    if args.pipeline > 0 and S == 1:
+        # Two batches in flight on disjoint CU sets (include/ohw.h, ohw_stream_create): while batch i decodes (HBM- and
+        # latency-bound, MFMA idle) batch i+1 runs mel + encoder + cross-K/V (MFMA-bound).  A step is still one whole
+        # pass over one batch of B windows; K steps are timed from the first mel to the last token, fill and drain included.
+        n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        if not 0 < args.pipeline < n_cu:
+            raise SystemExit(f"--pipeline must be in 1..{n_cu - 1}")
+        es, ds = E.Stream(local_rank, 0, args.pipeline), E.Stream(local_rank, args.pipeline, n_cu - args.pipeline)
+        full = E.Stream(local_rank, 0, 0)      # fill and drain run alone: every CU
+        pst = [st, E.State(ctx, B)]
+        pipe = {"encoder_cus": args.pipeline, "decoder_cus": n_cu - args.pipeline, "batches_in_flight": 2}
+
+        def enqueue_front(s_, stream):      # asynchronous: returns as soon as the launches are queued
+            s_.set_stream(stream.ptr)
+            s_.mel_device(pcm.data_ptr(), pcm.shape[1], n_samples, E.OHW_MEL_ZERO_TAIL)
+            s_.encode(B)
+
+        def run_steps(n):           # noqa: F811
+            toks = None
+            if n > 0:
+                enqueue_front(pst[0], full)
+                last_front = full
+            for i in range(n):
+                cur, nxt = pst[i % 2], pst[(i + 1) % 2]
+                dstream = ds if i + 1 < n else full
+                dstream.wait(last_front)         # batch i's cross-K/V is ready before its decode starts
+                if i + 1 < n:
+                    es.wait(last_front)          # (the first front end ran on the unrestricted stream)
+                    enqueue_front(nxt, es)       # batch i+1's front end runs beside batch i's decode
+                    last_front = es
+                cur.set_stream(dstream.ptr)
+                toks, _ = cur.greedy(B, p)       # host-blocking greedy loop (hipGraph replays on the decoder's stream)
+                if use_dist:
+                    shard.gather_tokens(shard.pack_tokens(toks, args.tokens), dist, world, rank, dev, force=True)
+            return toks
+
+    toks = run_steps(args.warmup)
 
     # ---- timed region: exactly K steps, no profiling hooks active (the decode loop replays its hipGraph)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        toks = step()
+    toks = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    if pipe:
+        # the same K steps one batch after the other (untimed for `value`; reported beside it, and the per-stage times
+        # below come from this leg, where the stages do not overlap)
+        st.set_stream(None)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        pipe["unpipelined_ms_per_step"] = round(1e3 * (time.perf_counter() - t1) / args.steps, 2)
+        pipe["unpipelined_value"] = round(30.0 * B * world * args.steps / (time.perf_counter() - t1), 1)   # rank 0's clock
     tm = st.timings()
 
     # ---- roofline leg (untimed, same workload): HIP events recorded on the launch stream around every
@@ -190,7 +245,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.model} dims, batch={B} x 30 s windows per GPU, greedy, {args.tokens} tokens/window (EOT suppressed), "
                                    f"procedural weights seed 1234, PCM resident in HBM", "model_dims": hp.as_list(),
-                       "concurrent_sub_batches": S_saved,
+                       "concurrent_sub_batches": S_saved, "pipeline": pipe,
                        "stage_ms_last_step": {"mel": round(tm.mel_ms, 2), "encode": round(tm.encode_ms, 2), "decode": round(tm.decode_ms, 2)},
                        "decode_steps": tm.decode_steps},
             "roofline": roof, "cpu_baseline": cpu,

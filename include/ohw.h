@@ -95,6 +95,17 @@ int ohw_state_set_stream(ohw_state* st, void* hip_stream);
 int ohw_state_max_batch(const ohw_state* st);
 const ohw_ctx* ohw_state_ctx(const ohw_state* st);
 
+/* ---- streams for two batches in flight (the reference has one state and no overlap: src/queue/worker.rs:100-160
+ *      transcribes one buffer at a time).  The encoder is MFMA-bound and the decoder HBM/latency-bound, so the engine
+ *      runs the encoder of batch i+1 beside the decoder of batch i on DISJOINT sets of compute units: a stream made here
+ *      is restricted to CU-mask bits [first_cu, first_cu + n_cu) (bits are dealt round-robin over the 8 XCDs, so any
+ *      contiguous range is spread evenly); n_cu = 0 makes an unrestricted stream.  ohw_stream_wait makes `waiter` wait
+ *      for everything enqueued on `signal` so far (event record + wait, no host sync). ------------------------------- */
+int ohw_stream_create(int device, int first_cu, int n_cu, void** stream_out);
+int ohw_stream_destroy(void* stream);
+int ohw_stream_wait(void* waiter, void* signal);
+int ohw_stream_sync(void* stream);
+
 /* ---- the stages of state.full() (reference src/engine/whisper.rs:266-268), split so that the   */
 /*      host keeps windowing and sampling (BASELINE.json north_star) ------------------------------ */
 

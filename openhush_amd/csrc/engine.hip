@@ -422,6 +422,51 @@ int ohw_state_set_stream(ohw_state* st, void* hip_stream) {
   });
 }
 
+int ohw_stream_create(int device, int first_cu, int n_cu, void** stream_out) {
+  return guard([&] {
+    if (!stream_out) throw Error(OHW_E_INVALID_ARG, "stream_out is null");
+    *stream_out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) throw Error(OHW_E_NO_GPU, "stream: bad device index");
+    HIP_CHECK(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    if (n_cu <= 0) {
+      HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    } else {
+      hipDeviceProp_t prop;
+      HIP_CHECK(hipGetDeviceProperties(&prop, device));
+      const int total = prop.multiProcessorCount;
+      if (first_cu < 0 || first_cu + n_cu > total) throw Error(OHW_E_INVALID_ARG, "stream: CU range exceeds the device's compute units");
+      std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
+      for (int b = first_cu; b < first_cu + n_cu; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
+      HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+    }
+    *stream_out = (void*)s;
+  });
+}
+int ohw_stream_destroy(void* stream) {
+  return guard([&] {
+    if (stream) HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+  });
+}
+int ohw_stream_wait(void* waiter, void* signal) {
+  return guard([&] {
+    if (!waiter || !signal) throw Error(OHW_E_INVALID_ARG, "stream is null");
+    hipEvent_t e = nullptr;
+    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipError_t r = hipEventRecord(e, (hipStream_t)signal);
+    if (r == hipSuccess) r = hipStreamWaitEvent((hipStream_t)waiter, e, 0);
+    (void)hipEventDestroy(e);   // released once the recorded work has completed
+    HIP_CHECK(r);
+  });
+}
+int ohw_stream_sync(void* stream) {
+  return guard([&] {
+    if (!stream) throw Error(OHW_E_INVALID_ARG, "stream is null");
+    HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  });
+}
+
 int ohw_state_max_batch(const ohw_state* st) { return st ? st->max_batch : 0; }
 const ohw_ctx* ohw_state_ctx(const ohw_state* st) { return st ? st->ctx : nullptr; }
 

@@ -63,6 +63,12 @@ struct ohw_engine {
   std::vector<int32_t> last_tokens;
   std::string last_text;
   std::vector<ohw_window_quality> last_quality;
+  // two batches in flight for audio longer than max_batch windows (include/ohw.h, ohw_stream_create): a second state
+  // and three streams, made on first use; enc_cus = 0 keeps the batches strictly one after the other
+  ohw_state* state2 = nullptr;
+  void* s_full = nullptr; void* s_enc = nullptr; void* s_dec = nullptr;
+  int enc_cus = 96;
+  int device = 0;
 };
 
 extern "C" {
@@ -214,6 +220,8 @@ int ohw_engine_new(const char* model_path, const char* language, int translate, 
     e->language = lang;
     e->translate = translate != 0;
     e->max_batch = std::max(1, max_batch);
+    e->device = device;
+    if (const char* ev = getenv("OHW_ENGINE_ENC_CUS")) e->enc_cus = std::max(0, atoi(ev));
     int rc = ohw_ctx_create(model_path, device, dtype, &e->ctx);
     if (rc != OHW_OK) throw Error(rc == OHW_E_MODEL_NOT_FOUND ? rc : (rc == OHW_E_NO_GPU || rc == OHW_E_OOM ? rc : OHW_E_LOAD_FAILED),
                                   "Failed to load model: " + g_last_error);
@@ -231,6 +239,8 @@ int ohw_engine_new(const char* model_path, const char* language, int translate, 
 void ohw_engine_free(ohw_engine* e) {
   if (!e) return;
   ohw_state_free(e->state);
+  if (e->state2) ohw_state_free(e->state2);
+  for (void* st : {e->s_full, e->s_enc, e->s_dec}) if (st) (void)ohw_stream_destroy(st);
   ohw_ctx_free(e->ctx);
   delete e;
 }
@@ -323,17 +333,77 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
       const int64_t n_win = (n + CHUNK_SAMPLES - 1) / CHUNK_SAMPLES;
       std::vector<int32_t> toks((size_t)e->max_batch * max_tok), ntok((size_t)e->max_batch), ns((size_t)e->max_batch);
       std::vector<float> slp((size_t)e->max_batch);
-      for (int64_t w0 = 0; w0 < n_win; w0 += e->max_batch) {
-        const int B = (int)std::min<int64_t>(e->max_batch, n_win - w0);
-        for (int b = 0; b < B; ++b) ns[(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + b) * CHUNK_SAMPLES);
-        int rc = ohw_mel(e->state, samples + w0 * CHUNK_SAMPLES, CHUNK_SAMPLES, ns.data(), B, 0, OHW_MEL_ZERO_TAIL, nullptr);
-        if (rc == OHW_OK) rc = ohw_encode(e->state, B);
-        if (rc == OHW_OK) rc = ohw_greedy(e->state, &sp, B, toks.data(), ntok.data(), max_tok, slp.data());
-        if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: " + g_last_error);   // reference :266-268
+      const int64_t n_batches = (n_win + e->max_batch - 1) / e->max_batch;
+      auto batch_of = [&](int64_t bi) { return (int)std::min<int64_t>(e->max_batch, n_win - bi * e->max_batch); };
+      auto collect = [&](int B) {
         for (int b = 0; b < B; ++b) {
           quality(&toks[(size_t)b * max_tok], ntok[(size_t)b], slp[(size_t)b]);
           append_text(&toks[(size_t)b * max_tok], ntok[(size_t)b]);
         }
+      };
+      bool pipelined = n_batches > 1 && e->enc_cus > 0;
+      if (pipelined && !e->state2) {
+        // first long input: the second state and the three streams (all CUs / encoder's share / decoder's share)
+        int rc = ohw_state_create(e->ctx, e->max_batch, &e->state2);
+        if (rc == OHW_OK) rc = ohw_stream_create(e->device, 0, 0, &e->s_full);
+        int total = 0;
+        if (rc == OHW_OK && hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) rc = OHW_E_TRANSCRIBE;
+        if (rc == OHW_OK && e->enc_cus >= total) rc = OHW_E_INVALID_ARG;
+        if (rc == OHW_OK) rc = ohw_stream_create(e->device, 0, e->enc_cus, &e->s_enc);
+        if (rc == OHW_OK) rc = ohw_stream_create(e->device, e->enc_cus, total - e->enc_cus, &e->s_dec);
+        if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed (pipeline set-up): " + g_last_error);
+      }
+      if (!pipelined) {
+        for (int64_t bi = 0; bi < n_batches; ++bi) {
+          const int64_t w0 = bi * e->max_batch;
+          const int B = batch_of(bi);
+          for (int b = 0; b < B; ++b) ns[(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + b) * CHUNK_SAMPLES);
+          int rc = ohw_mel(e->state, samples + w0 * CHUNK_SAMPLES, CHUNK_SAMPLES, ns.data(), B, 0, OHW_MEL_ZERO_TAIL, nullptr);
+          if (rc == OHW_OK) rc = ohw_encode(e->state, B);
+          if (rc == OHW_OK) rc = ohw_greedy(e->state, &sp, B, toks.data(), ntok.data(), max_tok, slp.data());
+          if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: " + g_last_error);   // reference :266-268
+          collect(B);
+        }
+      } else {
+        // mel + encoder + cross-K/V of batch i+1 (MFMA-bound) run beside the greedy decode of batch i (HBM- and
+        // latency-bound) on disjoint CUs; the first front end and the last decode have the device to themselves
+        ohw_state* sts[2] = {e->state, e->state2};
+        std::vector<int32_t> ns2[2] = {std::vector<int32_t>((size_t)e->max_batch), std::vector<int32_t>((size_t)e->max_batch)};
+        auto check = [&](int rc) { if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: " + g_last_error); };
+        auto restore = [&] { (void)ohw_state_set_stream(e->state, nullptr); (void)ohw_state_set_stream(e->state2, nullptr); };
+        auto front = [&](int64_t bi, void* stream) {
+          ohw_state* st = sts[bi & 1];
+          std::vector<int32_t>& nsv = ns2[bi & 1];
+          const int64_t w0 = bi * e->max_batch;
+          const int B = batch_of(bi);
+          for (int b = 0; b < B; ++b) nsv[(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + b) * CHUNK_SAMPLES);
+          check(ohw_state_set_stream(st, stream));
+          check(ohw_mel(st, samples + w0 * CHUNK_SAMPLES, CHUNK_SAMPLES, nsv.data(), B, 0, OHW_MEL_ZERO_TAIL, nullptr));
+          check(ohw_encode(st, B));
+        };
+        try {
+          front(0, e->s_full);
+          void* last_front = e->s_full;
+          for (int64_t bi = 0; bi < n_batches; ++bi) {
+            const bool more = bi + 1 < n_batches;
+            void* dstream = more ? e->s_dec : e->s_full;
+            check(ohw_stream_wait(dstream, last_front));            // this batch's cross-K/V before its decode
+            if (more) {
+              check(ohw_stream_wait(e->s_enc, last_front));
+              front(bi + 1, e->s_enc);
+              last_front = e->s_enc;
+            }
+            check(ohw_state_set_stream(sts[bi & 1], dstream));
+            const int B = batch_of(bi);
+            check(ohw_greedy(sts[bi & 1], &sp, B, toks.data(), ntok.data(), max_tok, slp.data()));
+            collect(B);
+          }
+        } catch (...) {
+          (void)hipDeviceSynchronize();
+          restore();
+          throw;
+        }
+        restore();
       }
     }
     // reference :282-283: trim

@@ -71,6 +71,7 @@ EXPORTS = [
     "ohw_engine_transcribe", "ohw_engine_last_tokens", "ohw_engine_benchmark", "ohw_engine_free", "ohw_engine_state",
     "ohw_engine_ctx", "ohw_lang_id_to_code", "ohw_lang_code_to_id", "ohw_last_error", "ohw_abi_version", "ohw_state_fetch",
     "ohw_dbg_gemm", "ohw_dbg_attention", "ohw_state_profile_begin", "ohw_state_profile_end", "ohw_ctx_weight_digest", "ohw_detect_language", "ohw_state_ctx", "ohw_engine_set_window_mode", "ohw_engine_last_text", "ohw_engine_last_quality",
+    "ohw_stream_create", "ohw_stream_destroy", "ohw_stream_wait", "ohw_stream_sync",
 ]
 
 
@@ -125,6 +126,10 @@ def lib():
         L.ohw_state_free.argtypes = [vp]
         L.ohw_state_free.restype = None
         L.ohw_state_set_stream.argtypes = [vp, vp]
+        L.ohw_stream_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        L.ohw_stream_destroy.argtypes = [vp]
+        L.ohw_stream_wait.argtypes = [vp, vp]
+        L.ohw_stream_sync.argtypes = [vp]
         L.ohw_state_max_batch.argtypes = [vp]
         L.ohw_mel.argtypes = [vp, vp, C.c_int64, ip, C.c_int, C.c_int, C.c_int, fp]
         L.ohw_encode.argtypes = [vp, C.c_int]
@@ -263,6 +268,34 @@ class Context:
         if getattr(self, "h", None):
             lib().ohw_ctx_free(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Stream:
+    """HIP stream restricted to CU-mask bits [first_cu, first_cu + n_cu) (n_cu = 0: all CUs); see include/ohw.h"""
+    def __init__(self, device: int = 0, first_cu: int = 0, n_cu: int = 0):
+        self.h = C.c_void_p()
+        _check(lib().ohw_stream_create(device, first_cu, n_cu, C.byref(self.h)))
+
+    @property
+    def ptr(self) -> int:
+        return self.h.value or 0
+
+    def wait(self, other: "Stream"):
+        _check(lib().ohw_stream_wait(self.h, other.h))
+
+    def sync(self):
+        _check(lib().ohw_stream_sync(self.h))
+
+    def close(self):
+        if self.h:
+            lib().ohw_stream_destroy(self.h)
+            self.h = C.c_void_p()
 
     def __del__(self):
         try:

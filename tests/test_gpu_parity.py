@@ -280,6 +280,24 @@ class _Ctx:
         self.h = eng.ctx_h
 
 
+def test_long_audio_two_batches_in_flight_equals_sequential(E, models, monkeypatch):
+    """ohw_engine_transcribe on audio longer than max_batch windows overlaps the front end of batch i+1 with the decode of
+    batch i on disjoint CU sets (include/ohw.h, ohw_stream_create): same tokens as one batch after the other."""
+    _, path, _, _ = models
+    pcm = np.concatenate([synth.synth_audio(30 + w) for w in range(5)] + [synth.synth_audio(36, 200000)])   # 6 windows, 3 batches
+    out = {}
+    for cus in ("0", "96", "200"):
+        monkeypatch.setenv("OHW_ENGINE_ENC_CUS", cus)          # read when the engine is created; 0 = strictly sequential
+        eng = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_BF16, 2)
+        r1 = eng.transcribe(E.AudioBuffer(pcm, 16000))
+        t1 = eng.last_tokens()
+        r2 = eng.transcribe(E.AudioBuffer(pcm[:480000 * 3 + 1000], 16000))     # the states and streams are reused
+        out[cus] = (r1.text, t1, r2.text, eng.last_tokens(), [q[0] for q in eng.last_quality()])
+        eng.close()
+    assert out["96"] == out["0"] and out["200"] == out["0"]
+    assert len(out["0"][4]) == 4
+
+
 def test_engine_error_paths(E, tmp_path):
     with pytest.raises(E.ModelNotFound) as ei:
         E.WhisperEngine.new(str(tmp_path / "ggml-small.bin"), "auto", False, True)
