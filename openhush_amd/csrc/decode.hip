@@ -367,10 +367,12 @@ static void dec_gemm_launch(const DecGemmParams& p, hipStream_t s) {
 
 template <typename T, int EPI, bool LN>
 static void dec_gemm_pick(const DecGemmParams& p, hipStream_t s) {
-  // with the LayerNorm image in LDS one workgroup fills a CU: keep the grid within one wave of 256 CUs
+  // with the LayerNorm image in LDS one workgroup fills a CU: keep the grid within one wave of the CUs this
+  // launch may use (256, or the decoder's share when two batches are in flight)
   const int n_tiles = (p.N + 15) / 16;
   static const int logits_nt = getenv("OHW_LOGITS_NT") ? atoi(getenv("OHW_LOGITS_NT")) : 2;
-  if ((LN && n_tiles > 256) || (EPI == DEPI_LOGITS && logits_nt == 2)) dec_gemm_launch<T, EPI, LN, 2>(p, s);
+  const int cus = p.cu_budget > 0 ? p.cu_budget : 256;
+  if ((LN && n_tiles > cus) || (EPI == DEPI_LOGITS && logits_nt == 2)) dec_gemm_launch<T, EPI, LN, 2>(p, s);
   else dec_gemm_launch<T, EPI, LN, 1>(p, s);
 }
 

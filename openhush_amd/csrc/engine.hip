@@ -77,6 +77,7 @@ struct ohw_state {
   DevBuf dx, dy, dq, da, df, logits;
   DevBuf ks_slab, ks_ticket;   // split-K partial tiles and arrival tickets of the decoder's RESID GEMMs
   int ksplit_long = 1, ksplit_short = 1;
+  int stream_cus = 0;            // CUs of the current stream's mask (0 = unrestricted)
   DevBuf samp_part, samp_ticket;   // sampler: per-slice partial states and arrival tickets
   DevBuf step_tok, n_past, tokens, n_cur, next_tok, done, n_done, sum_lp;
   int m_max = 0;
@@ -90,6 +91,7 @@ struct ohw_state {
   hipGraph_t step_graph = nullptr;
   hipGraphExec_t step_exec = nullptr;
   int graph_batch = 0;
+  int graph_cus = 0;
   SamplerParams graph_spar{};
   bool graphs_enabled = true;
   // timing
@@ -267,6 +269,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
     DecGemmParams p{};
     p.x = x; p.w = w.p; p.bias = bias.p ? bias.as<float>() : nullptr; p.out = out;
     p.ln = ln ? 1 : 0;
+    p.cu_budget = st->stream_cus;
     if (epi == DEPI_BIAS_RESID) {
       const int ks = K >= 2 * d ? st->ksplit_long : st->ksplit_short;
       if (ks > 1 && ks <= K / 32) {
@@ -289,7 +292,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
     T* vc = kc + kv_layer;
     {  // LN1 + fused QKV projection; K/V go straight into the cache at each window's position
       DecGemmParams p{};
-      p.x = st->dx.p; p.ln = 1;
+      p.x = st->dx.p; p.ln = 1; p.cu_budget = st->stream_cus;
       p.w = w.wqkv.p; p.bias = w.bqkv.as<float>(); p.out = st->dq.p;
       p.M = M; p.N = 3 * d; p.K = d; p.n_new = n_new; p.ld_out = d;
       p.k_cache = kc; p.v_cache = vc; p.n_past = n_past; p.d_model = d; p.n_head = H; p.n_ctx = C;
@@ -419,6 +422,22 @@ int ohw_state_set_stream(ohw_state* st, void* hip_stream) {
   return guard([&] {
     if (!st) throw Error(OHW_E_INVALID_ARG, "state is null");
     st->stream = hip_stream ? (hipStream_t)hip_stream : st->own_stream;
+    st->stream_cus = 0;
+    if (hip_stream) {
+      uint32_t mask[16] = {0};
+      if (hipExtStreamGetCUMask(st->stream, 16, mask) == hipSuccess) {
+        int n = 0, total = 0;
+        for (uint32_t m : mask) n += __builtin_popcount(m);
+        (void)hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, st->ctx->device);
+        if (n > 0 && n < total) st->stream_cus = n;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    if (st->stream_cus != st->graph_cus && st->step_exec) {      // the captured grids depend on the CU budget
+      (void)hipGraphExecDestroy(st->step_exec); st->step_exec = nullptr;
+      if (st->step_graph) { (void)hipGraphDestroy(st->step_graph); st->step_graph = nullptr; }
+    }
   });
 }
 
@@ -613,6 +632,7 @@ int ohw_greedy(ohw_state* st, const ohw_sample_params* sp, int batch, int32_t* t
         HIP_CHECK(hipStreamEndCapture(s, &st->step_graph));
         HIP_CHECK(hipGraphInstantiate(&st->step_exec, st->step_graph, nullptr, nullptr, 0));
         st->graph_batch = batch;
+        st->graph_cus = st->stream_cus;
         st->graph_spar = spar;
       }
       int32_t n_done_host = 0;

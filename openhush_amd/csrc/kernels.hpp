@@ -59,6 +59,7 @@ struct DecGemmParams {
   const int32_t* n_past;            // device [B]
   int32_t d_model, n_head, n_ctx;
   int64_t ld_out;
+  int32_t cu_budget;                // compute units the launch may use (0 = the whole device); picks n-tiles per workgroup
   // DEPI_BIAS_RESID with ksplit > 1: K is split over ksplit workgroups per output tile (see decode.hip)
   int32_t ksplit;                   // 0 / 1 = off
   int32_t slab_bytes;
