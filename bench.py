@@ -142,11 +142,16 @@ def main():
         n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
         if not 0 < args.pipeline < n_cu:
             raise SystemExit(f"--pipeline must be in 1..{n_cu - 1}")
-        es, ds = E.Stream(local_rank, 0, args.pipeline), E.Stream(local_rank, args.pipeline, n_cu - args.pipeline)
-        full = E.Stream(local_rank, 0, 0)      # fill and drain run alone: every CU
-        pst = [st, E.State(ctx, B)]
-        pipe = {"encoder_cus": args.pipeline, "decoder_cus": n_cu - args.pipeline, "batches_in_flight": 2}
+        try:
+            es, ds = E.Stream(local_rank, 0, args.pipeline), E.Stream(local_rank, args.pipeline, n_cu - args.pipeline)
+            full = E.Stream(local_rank, 0, 0)      # fill and drain run alone: every CU
+            pst = [st, E.State(ctx, B)]
+            pipe = {"encoder_cus": args.pipeline, "decoder_cus": n_cu - args.pipeline, "batches_in_flight": 2}
+        except E.WhisperError as ex:               # no CU-masked queues on this box: one batch after the other
+            print(f"[bench] two-batch pipeline unavailable ({ex}); running one batch after the other", file=sys.stderr, flush=True)
+            pipe = None
 
+    if pipe:
         def enqueue_front(s_, stream):      # asynchronous: returns as soon as the launches are queued
             s_.set_stream(stream.ptr)
             s_.mel_device(pcm.data_ptr(), pcm.shape[1], n_samples, E.OHW_MEL_ZERO_TAIL)

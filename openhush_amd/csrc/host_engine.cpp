@@ -351,7 +351,13 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
         if (rc == OHW_OK && e->enc_cus >= total) rc = OHW_E_INVALID_ARG;
         if (rc == OHW_OK) rc = ohw_stream_create(e->device, 0, e->enc_cus, &e->s_enc);
         if (rc == OHW_OK) rc = ohw_stream_create(e->device, e->enc_cus, total - e->enc_cus, &e->s_dec);
-        if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed (pipeline set-up): " + g_last_error);
+        if (rc != OHW_OK) {
+          // no CU-masked queues (or no memory for the second state) here: one batch after the other from now on
+          if (e->state2) { ohw_state_free(e->state2); e->state2 = nullptr; }
+          for (void** st : {&e->s_full, &e->s_enc, &e->s_dec}) if (*st) { (void)ohw_stream_destroy(*st); *st = nullptr; }
+          e->enc_cus = 0;
+          pipelined = false;
+        }
       }
       if (!pipelined) {
         for (int64_t bi = 0; bi < n_batches; ++bi) {
