@@ -68,8 +68,12 @@ constexpr int DG_THREADS = 512;
 constexpr int DG_WAVES = DG_THREADS / 64;
 constexpr int DG_LN_MAXK = 1280;  // fused LayerNorm: 16 threads per row, 20 float4 each
 
-template <typename T, int EPI, bool LN, int NT>
+template <typename T, int EPI, bool LN, int NT, int MT>
 __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p) {
+  // MT = m-tiles (16 rows) per workgroup.  MT = 1 (RESID GEMMs): the two row halves of a weight tile go to two
+  // workgroups on the same XCD (the second reads the weights from L2), each pulling half the activation bytes - per-CU
+  // ingest, not HBM, bounds these launches.
+  static_assert(MT == 1 || MT == 2, "MT");
   using Ops = TypeOps<T>;
   using vec8 = typename Ops::vec8;
   extern __shared__ __attribute__((aligned(16))) unsigned char dg_smem[];
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   unsigned char* ylds = dg_smem + DG_WAVES * NT * 2 * 64 * 16;        // LN: [32][K*2 + 16] bytes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt0 = blockIdx.x * NT;
-  const int m0 = blockIdx.y * 32;
+  const int m0 = blockIdx.y * 16 * MT;
   const int kblocks = p.K / 32;
   const int ystride = p.K * 2 + 16;
   const int n_tiles = (p.N + 15) / 16;
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   // epilogue coordinates are known up front: one output per thread and n-tile
   const int e_mt = tid >> 8, e_ll = (tid >> 2) & 63, e_reg = tid & 3;
   const int e_m = m0 + e_mt * 16 + (e_ll & 15);
+  const bool e_active = MT == 2 || e_mt == 0;
   // split-K (RESID only, gridDim.z slices): this workgroup owns k-blocks [k_lo, k_hi)
   const int ksplit = gridDim.z;
   const int k_lo = (int)((int64_t)kblocks * blockIdx.z / ksplit), k_hi = (int)((int64_t)kblocks * (blockIdx.z + 1) / ksplit);
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int n = (nt0 + t) * 16 + 4 * (e_ll >> 4) + e_reg;
-      resid_old[t] = (e_m < p.M && n < p.N) ? ((const float*)p.out)[(int64_t)e_m * p.ld_out + n] : 0.f;
+      resid_old[t] = (e_active && e_m < p.M && n < p.N) ? ((const float*)p.out)[(int64_t)e_m * p.ld_out + n] : 0.f;
     }
   }
 
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
         b[u] = *(const vec8*)(y1 + kk * 64);
       } else {
         a[u] = *(const vec8*)(x0 + (int64_t)kk * 512);
-        b[u] = *(const vec8*)(x1 + (int64_t)kk * 512);
+        if constexpr (MT == 2) b[u] = *(const vec8*)(x1 + (int64_t)kk * 512);
       }
     }
     // keep every load above issued before the first MFMA (the scheduler otherwise sinks loads next to
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         acc[t][0] = Ops::mfma16(w[t][u], a[u], acc[t][0]);
-        acc[t][1] = Ops::mfma16(w[t][u], b[u], acc[t][1]);
+        if constexpr (MT == 2) acc[t][1] = Ops::mfma16(w[t][u], b[u], acc[t][1]);
       }
   };
   if constexpr (LN) {
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
         for (int u = 0; u < 5; ++u) {
           const int kk = kb + DG_WAVES * (g + u);
           a[u] = *(const vec8*)(x0 + (int64_t)kk * 512);
-          b[u] = *(const vec8*)(x1 + (int64_t)kk * 512);
+          if constexpr (MT == 2) b[u] = *(const vec8*)(x1 + (int64_t)kk * 512);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             acc[t][0] = Ops::mfma16(w[t][g + u], a[u], acc[t][0]);
-            acc[t][1] = Ops::mfma16(w[t][g + u], b[u], acc[t][1]);
+            if constexpr (MT == 2) acc[t][1] = Ops::mfma16(w[t][g + u], b[u], acc[t][1]);
           }
       }
     }
@@ -273,10 +278,10 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     part[((wave * NT + t) * 2 + 0) * 64 + lane] = acc[t][0];
-    part[((wave * NT + t) * 2 + 1) * 64 + lane] = acc[t][1];
+    if constexpr (MT == 2) part[((wave * NT + t) * 2 + 1) * 64 + lane] = acc[t][1];
   }
   __syncthreads();
-  if constexpr (EPI == DEPI_BIAS_RESID && NT == 1) {
+  if constexpr (EPI == DEPI_BIAS_RESID && NT == 1 && MT == 2) {
     if (ksplit > 1) {
       // Cross-workgroup split-K without spinning and without float atomics: every slice writes its 32 x 16 partial
       // tile through to memory (sc1 stores, drained), takes a ticket, and the slice that draws the last ticket sums
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
     for (int w = 0; w < DG_WAVES; ++w) v += pp[(((w * NT + t) * 2 + e_mt) * 64 + e_ll) * 4 + e_reg];
     const int n = (nt0 + t) * 16 + 4 * (e_ll >> 4) + e_reg;
     const int m = e_m;
-    if (m >= p.M || n >= p.N || nt0 + t >= n_tiles) continue;
+    if (!e_active || m >= p.M || n >= p.N || nt0 + t >= n_tiles) continue;
     if (p.bias) v += p.bias[n];
     if constexpr (EPI == DEPI_QKV) {
       const int d = p.d_model;
@@ -356,13 +361,13 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   TRACE(16 + EPI * 2 + (LN ? 1 : 0), 3);
 }
 
-template <typename T, int EPI, bool LN, int NT>
+template <typename T, int EPI, bool LN, int NT, int MT>
 static void dec_gemm_launch(const DecGemmParams& p, hipStream_t s) {
   const int n_tiles = (p.N + 15) / 16;
-  dim3 grid((n_tiles + NT - 1) / NT, (p.M + 31) / 32, p.ksplit > 1 ? p.ksplit : 1);
+  dim3 grid((n_tiles + NT - 1) / NT, (p.M + 16 * MT - 1) / (16 * MT), p.ksplit > 1 ? p.ksplit : 1);
   const size_t smem = (size_t)DG_WAVES * NT * 2 * 64 * 16 + (LN ? (size_t)32 * (p.K * 2 + 16) : 0);
-  if (LN) ensure_dynamic_lds((const void*)dec_gemm_kernel<T, EPI, LN, NT>, 160 * 1024);
-  hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, LN, NT>), grid, dim3(DG_THREADS), smem, s, p);
+  if (LN) ensure_dynamic_lds((const void*)dec_gemm_kernel<T, EPI, LN, NT, MT>, 160 * 1024);
+  hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, LN, NT, MT>), grid, dim3(DG_THREADS), smem, s, p);
 }
 
 template <typename T, int EPI, bool LN>
@@ -371,9 +376,14 @@ static void dec_gemm_pick(const DecGemmParams& p, hipStream_t s) {
   // launch may use (256, or the decoder's share when two batches are in flight)
   const int n_tiles = (p.N + 15) / 16;
   static const int logits_nt = getenv("OHW_LOGITS_NT") ? atoi(getenv("OHW_LOGITS_NT")) : 2;
+  static const int msplit = getenv("OHW_DEC_MSPLIT") ? atoi(getenv("OHW_DEC_MSPLIT")) : 1;
   const int cus = p.cu_budget > 0 ? p.cu_budget : 256;
-  if ((LN && n_tiles > cus) || (EPI == DEPI_LOGITS && logits_nt == 2)) dec_gemm_launch<T, EPI, LN, 2>(p, s);
-  else dec_gemm_launch<T, EPI, LN, 1>(p, s);
+  if constexpr (EPI == DEPI_BIAS_RESID && !LN) {
+    // one m-tile per workgroup when that still fits one wave of CUs (and the hand-off path is not in use)
+    if (msplit && p.M > 16 && p.ksplit <= 1 && n_tiles * ((p.M + 15) / 16) <= 2 * cus) { dec_gemm_launch<T, EPI, LN, 1, 1>(p, s); return; }
+  }
+  if ((LN && n_tiles > cus) || (EPI == DEPI_LOGITS && logits_nt == 2)) dec_gemm_launch<T, EPI, LN, 2, 2>(p, s);
+  else dec_gemm_launch<T, EPI, LN, 1, 2>(p, s);
 }
 
 template <typename T>
