@@ -127,47 +127,48 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   }
 
   if constexpr (LN) {
-    // all 512 threads: row = tid / 16, 16 threads per row, every load of the 32 x K tile in flight at once
+    // all 512 threads: 16 * MT rows, TPR = 32 / MT threads per row, every load of the tile in flight at once
     const float* __restrict__ xf = (const float*)p.x;
-    const int row = tid >> 4, sub = tid & 15;
+    constexpr int TPR = 32 / MT;
+    const int row = tid / TPR, sub = tid % TPR;
     int m = m0 + row;
     if (m > p.M - 1) m = p.M - 1;
     const float* xr = xf + (int64_t)m * p.K;
-    constexpr int NV = DG_LN_MAXK / 64;
+    constexpr int NV = DG_LN_MAXK / (4 * TPR);
     // every load is unconditional (clamped column, masked value): a per-element "load or zero" branch
     // makes hipcc wait vmcnt(0) per element and serialises 20 L2 round trips
     f32x4 v[NV];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = (i * 16 + sub) * 4;
+      const int c = (i * TPR + sub) * 4;
       const int cc = c < p.K ? c : 0;
       v[i] = *(const f32x4*)(xr + cc);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = (i * 16 + sub) * 4;
+      const int c = (i * TPR + sub) * 4;
       const float ok = c < p.K ? 1.f : 0.f;
       sum += ok * ((v[i].x + v[i].y) + (v[i].z + v[i].w));
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    for (int o = TPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float mean = sum / (float)p.K;
     float var = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = (i * 16 + sub) * 4;
+      const int c = (i * TPR + sub) * 4;
       const float ok = c < p.K ? 1.f : 0.f;
       const float a = v[i].x - mean, b2 = v[i].y - mean, c2 = v[i].z - mean, d2 = v[i].w - mean;
       var += ok * ((a * a + b2 * b2) + (c2 * c2 + d2 * d2));
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    for (int o = TPR / 2; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
     const float rstd = rsqrtf(var / (float)p.K + 1e-5f);
     // gamma / beta live in the weights and the bias (launch_fold_ln): only the normalisation is left here
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = (i * 16 + sub) * 4;
+      const int c = (i * TPR + sub) * 4;
       u32x2 w2;
       w2.x = pack2<T>((v[i].x - mean) * rstd, (v[i].y - mean) * rstd);
       w2.y = pack2<T>((v[i].z - mean) * rstd, (v[i].w - mean) * rstd);
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
       const int kk = kb + DG_WAVES * u;
       if constexpr (LN) {
         a[u] = *(const vec8*)(y0 + kk * 64);
-        b[u] = *(const vec8*)(y1 + kk * 64);
+        if constexpr (MT == 2) b[u] = *(const vec8*)(y1 + kk * 64);
       } else {
         a[u] = *(const vec8*)(x0 + (int64_t)kk * 512);
         if constexpr (MT == 2) b[u] = *(const vec8*)(x1 + (int64_t)kk * 512);
@@ -223,10 +224,10 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
       const int kk = wave + DG_WAVES * u;
       const int kc = kk < kblocks ? kk : 0;
       a[u] = *(const vec8*)(y0 + kc * 64);
-      b[u] = *(const vec8*)(y1 + kc * 64);
+      if constexpr (MT == 2) b[u] = *(const vec8*)(y1 + kc * 64);
       if (kk >= kblocks) {   // register select, not a load branch: blocks past K contribute zero
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { a[u][e] = 0; b[u][e] = 0; }
+        for (int e = 0; e < 8; ++e) { a[u][e] = 0; if constexpr (MT == 2) b[u][e] = 0; }
       }
     }
 #pragma unroll
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         acc[t][0] = Ops::mfma16(wpre[t][u], a[u], acc[t][0]);
-        acc[t][1] = Ops::mfma16(wpre[t][u], b[u], acc[t][1]);
+        if constexpr (MT == 2) acc[t][1] = Ops::mfma16(wpre[t][u], b[u], acc[t][1]);
       }
   } else {
     int kb = k_lo + wave;
@@ -365,7 +366,7 @@ template <typename T, int EPI, bool LN, int NT, int MT>
 static void dec_gemm_launch(const DecGemmParams& p, hipStream_t s) {
   const int n_tiles = (p.N + 15) / 16;
   dim3 grid((n_tiles + NT - 1) / NT, (p.M + 16 * MT - 1) / (16 * MT), p.ksplit > 1 ? p.ksplit : 1);
-  const size_t smem = (size_t)DG_WAVES * NT * 2 * 64 * 16 + (LN ? (size_t)32 * (p.K * 2 + 16) : 0);
+  const size_t smem = (size_t)DG_WAVES * NT * 2 * 64 * 16 + (LN ? (size_t)16 * MT * (p.K * 2 + 16) : 0);
   if (LN) ensure_dynamic_lds((const void*)dec_gemm_kernel<T, EPI, LN, NT, MT>, 160 * 1024);
   hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, LN, NT, MT>), grid, dim3(DG_THREADS), smem, s, p);
 }
@@ -381,6 +382,15 @@ static void dec_gemm_pick(const DecGemmParams& p, hipStream_t s) {
   if constexpr (EPI == DEPI_BIAS_RESID && !LN) {
     // one m-tile per workgroup when that still fits one wave of CUs (and the hand-off path is not in use)
     if (msplit && p.M > 16 && p.ksplit <= 1 && n_tiles * ((p.M + 15) / 16) <= 2 * cus) { dec_gemm_launch<T, EPI, LN, 1, 1>(p, s); return; }
+  }
+  if constexpr (LN) {
+    // one m-tile per workgroup halves the fp32 rows a workgroup normalises; pick the n-tiles per workgroup that keep
+    // the grid within one wave of CUs
+    const int mt = (p.M + 15) / 16;
+    if (msplit && p.M > 16 && mt == 2) {
+      if (n_tiles * mt <= cus) { dec_gemm_launch<T, EPI, LN, 1, 1>(p, s); return; }
+      if ((n_tiles + 1) / 2 * mt <= cus) { dec_gemm_launch<T, EPI, LN, 2, 1>(p, s); return; }
+    }
   }
   if ((LN && n_tiles > cus) || (EPI == DEPI_LOGITS && logits_nt == 2)) dec_gemm_launch<T, EPI, LN, 2, 2>(p, s);
   else dec_gemm_launch<T, EPI, LN, 1, 2>(p, s);
