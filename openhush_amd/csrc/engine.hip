@@ -88,11 +88,9 @@ struct ohw_state {
   size_t prof_used = 0;
   double prof_work = 0.0;
   // hipGraph of one greedy iteration {feed sampled token, single-token decoder step, sampler}
-  hipGraph_t step_graph = nullptr;
-  hipGraphExec_t step_exec = nullptr;
-  int graph_batch = 0;
-  int graph_cus = 0;
-  SamplerParams graph_spar{};
+  // captured greedy iterations, one per (batch, sampler parameters, CU budget of the stream) seen; a handful at most
+  struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int batch = 0; int cus = 0; SamplerParams spar{}; };
+  std::vector<StepGraph> step_graphs;
   bool graphs_enabled = true;
   // timing
   hipEvent_t ev[6]{};
@@ -412,8 +410,10 @@ void ohw_state_free(ohw_state* st) {
   (void)hipDeviceSynchronize();
   for (auto& e : st->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : st->prof_ev) if (e) (void)hipEventDestroy(e);
-  if (st->step_exec) (void)hipGraphExecDestroy(st->step_exec);
-  if (st->step_graph) (void)hipGraphDestroy(st->step_graph);
+  for (auto& g : st->step_graphs) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+  }
   if (st->own_stream) (void)hipStreamDestroy(st->own_stream);
   delete st;
 }
@@ -434,10 +434,7 @@ int ohw_state_set_stream(ohw_state* st, void* hip_stream) {
         (void)hipGetLastError();
       }
     }
-    if (st->stream_cus != st->graph_cus && st->step_exec) {      // the captured grids depend on the CU budget
-      (void)hipGraphExecDestroy(st->step_exec); st->step_exec = nullptr;
-      if (st->step_graph) { (void)hipGraphDestroy(st->step_graph); st->step_graph = nullptr; }
-    }
+
   });
 }
 
@@ -615,9 +612,19 @@ int ohw_greedy(ohw_state* st, const ohw_sample_params* sp, int batch, int32_t* t
       // short kernels), so it is captured once into a hipGraph and replayed; positions, tokens and
       // the done flags live in device memory, so the same graph serves every iteration.
       const bool use_graph = st->graphs_enabled && st->prof_class == 0 && s != nullptr;
-      if (use_graph && (!st->step_exec || st->graph_batch != batch || std::memcmp(&st->graph_spar, &spar, sizeof spar) != 0)) {
-        if (st->step_exec) { (void)hipGraphExecDestroy(st->step_exec); st->step_exec = nullptr; }
-        if (st->step_graph) { (void)hipGraphDestroy(st->step_graph); st->step_graph = nullptr; }
+      hipGraphExec_t step_exec = nullptr;
+      if (use_graph) {
+        for (auto& g : st->step_graphs)
+          if (g.batch == batch && g.cus == st->stream_cus && std::memcmp(&g.spar, &spar, sizeof spar) == 0) step_exec = g.exec;
+      }
+      if (use_graph && !step_exec) {
+        if (st->step_graphs.size() >= 8) {     // bounded: drop the oldest capture
+          auto& g = st->step_graphs.front();
+          if (g.exec) (void)hipGraphExecDestroy(g.exec);
+          if (g.graph) (void)hipGraphDestroy(g.graph);
+          st->step_graphs.erase(st->step_graphs.begin());
+        }
+        ohw_state::StepGraph ng;
         HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         try {
           HIP_CHECK(hipMemcpyAsync(st->step_tok.p, st->next_tok.p, (size_t)batch * 4, hipMemcpyDeviceToDevice, s));
@@ -629,16 +636,17 @@ int ohw_greedy(ohw_state* st, const ohw_sample_params* sp, int batch, int32_t* t
           if (g) (void)hipGraphDestroy(g);
           throw;
         }
-        HIP_CHECK(hipStreamEndCapture(s, &st->step_graph));
-        HIP_CHECK(hipGraphInstantiate(&st->step_exec, st->step_graph, nullptr, nullptr, 0));
-        st->graph_batch = batch;
-        st->graph_cus = st->stream_cus;
-        st->graph_spar = spar;
+        HIP_CHECK(hipStreamEndCapture(s, &ng.graph));
+        hipError_t ie = hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) { (void)hipGraphDestroy(ng.graph); HIP_CHECK(ie); }
+        ng.batch = batch; ng.cus = st->stream_cus; ng.spar = spar;
+        st->step_graphs.push_back(ng);
+        step_exec = ng.exec;
       }
       int32_t n_done_host = 0;
       for (int it = 1; it < n_max; ++it) {
         if (use_graph) {
-          HIP_CHECK(hipGraphLaunch(st->step_exec, s));
+          HIP_CHECK(hipGraphLaunch(step_exec, s));
         } else {
           HIP_CHECK(hipMemcpyAsync(st->step_tok.p, st->next_tok.p, (size_t)batch * 4, hipMemcpyDeviceToDevice, s));
           run_decoder_step<T>(st, batch, 1);
