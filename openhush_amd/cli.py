@@ -7,11 +7,17 @@ Only 16 kHz input is accepted here: the reference resamples with the `rubato` si
 the DSP front end (out of scope).
 
     python -m openhush_amd.cli transcribe audio.wav --model-path /path/ggml-small.bin [--format json]
+
+Long recordings over several GPUs of one node (BASELINE.json config #4): launch the same command under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m openhush_amd.cli transcribe ...`;
+the 30 s windows are dealt round-robin to the ranks (one GPU each), the token ids are gathered on rank 0 (RCCL), which
+prints the result (openhush_amd/shard.py).
 """
 from __future__ import annotations
 
 import argparse
 import json
+import os
 import struct
 import sys
 import time
@@ -51,6 +57,44 @@ def load_wav_file(path: str) -> np.ndarray:
     return np.ascontiguousarray(s, dtype=np.float32)
 
 
+def _transcribe_ranks(args, audio) -> int:
+    """one process per GPU under torch.distributed.run: shard the windows, gather the tokens, rank 0 prints"""
+    import torch
+    import torch.distributed as dist
+    from . import engine as E, shard
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    E.validate_audio(audio.samples, audio.sample_rate)
+    ctx = E.Context.from_file(args.model_path, local, E.OHW_DTYPE_BF16 if args.dtype == "bf16" else E.OHW_DTYPE_F16)
+    p = ctx.default_params()
+    if args.language != "auto":
+        p.lang_id = E.lang_code_to_id(args.language)
+    p.translate = 1 if args.translate else 0
+    n_win = (len(audio.samples) + E.CHUNK_SAMPLES - 1) // E.CHUNK_SAMPLES
+    t1 = time.perf_counter()
+    wins = shard.transcribe_sharded(shard.engine_window_runner(ctx, args.max_batch, p), audio.samples, n_win, ctx.hp.n_text_ctx,
+                                    dist, world, rank, torch.device("cuda", local))
+    dt = time.perf_counter() - t1
+    if rank == 0:
+        text = b"".join(ctx.token_text(t) for w in wins for t in w if t < ctx.tok.eot).decode("utf-8", "replace").strip()
+        lang = "en" if args.language == "auto" else args.language
+        name = args.model or args.model_path.rsplit("/", 1)[-1].replace("ggml-", "").rsplit(".", 1)[0]
+        if args.format == "json":
+            print(json.dumps({"text": text, "language": lang, "duration_ms": int(dt * 1e3), "audio_duration_secs": audio.duration_secs(),
+                              "transcription_time_ms": int(dt * 1e3), "real_time_factor": dt / audio.duration_secs(),
+                              "model": name.lower(), "gpus": world}, indent=2))
+        else:
+            print("\n--- Transcription ---")
+            print(text)
+            print("---")
+            print(f"\nTime: {dt * 1e3:.0f}ms (RTF: {dt / audio.duration_secs():.3f}x) on {world} GPUs")
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="openhush_amd.cli")
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -68,6 +112,8 @@ def main(argv=None) -> int:
 
     from . import engine as E
     audio = E.AudioBuffer(load_wav_file(args.file), SAMPLE_RATE)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return _transcribe_ranks(args, audio)
     use_gpu = args.device.lower() != "cpu"                    # reference src/main.rs:1037
     dev = int(args.device.split(":")[1]) if ":" in args.device else 0
     t0 = time.perf_counter()

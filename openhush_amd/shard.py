@@ -52,3 +52,52 @@ def interleave(per_rank: Sequence[List[List[int]]], n_windows: int, world: int) 
             if w < n_windows:
                 out[w] = t
     return out
+
+
+def transcribe_sharded(transcribe_windows, pcm, n_windows: int, width: int, dist, world: int, rank: int,
+                       device: Optional[torch.device] = None):
+    """One long recording over `world` ranks (BASELINE.json config #4: 1 h = 120 x 30 s windows over 8 GPUs).
+
+    pcm: the whole recording (1-D float32, 16 kHz), present on every rank; fixed 30 s cuts, window i -> rank i % world.
+    transcribe_windows(list of 1-D sample arrays) -> list of token lists runs this rank's windows through the engine
+    (it chooses its own batching).  No collective in the data path; the one gather brings the token ids to rank 0,
+    which returns the per-window token lists in recording order (other ranks return None)."""
+    chunk = 480000
+    mine = assign_windows(n_windows, world, rank)
+    toks = transcribe_windows([pcm[w * chunk:(w + 1) * chunk] for w in mine]) if mine else []
+    if len(toks) != len(mine):
+        raise RuntimeError("transcribe_windows must return one token list per window")
+    rows = (n_windows + world - 1) // world             # equal shapes for the gather: pad with empty windows
+    packed = pack_tokens(list(toks) + [[] for _ in range(rows - len(mine))], width)
+    got = gather_tokens(packed, dist, world, rank, device)
+    if rank != 0:
+        return None
+    return interleave([unpack_tokens(g) for g in got], n_windows, world)
+
+
+def engine_window_runner(ctx, max_batch: int, params=None, mel_mode: Optional[int] = None):
+    """transcribe_windows for transcribe_sharded on top of the staged C ABI: batches of up to max_batch windows through
+    mel -> encode -> greedy on this rank's device (the fixed-window path of ohw_engine_transcribe)."""
+    import numpy as np
+    from . import engine as E
+    st = E.State(ctx, max_batch)
+    p = params or ctx.default_params()
+    mode = E.OHW_MEL_ZERO_TAIL if mel_mode is None else mel_mode
+
+    def run(windows):
+        out = []
+        for i in range(0, len(windows), max_batch):
+            group = windows[i:i + max_batch]
+            buf = np.zeros((len(group), E.CHUNK_SAMPLES), np.float32)
+            ns = []
+            for b, w in enumerate(group):
+                buf[b, :len(w)] = w
+                ns.append(len(w))
+            st.mel(buf, ns, mode, want=False)
+            st.encode(len(group))
+            toks, _ = st.greedy(len(group), p)
+            out += toks
+        return out
+
+    return run
+

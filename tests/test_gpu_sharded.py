@@ -1,0 +1,52 @@
+"""BASELINE.json config #4 in miniature on ONE GPU: two gloo ranks (two processes sharing cuda:0) split the fixed 30 s
+windows of one recording, run them through the HIP engine and gather the token ids on rank 0 - the result equals the
+single-process engine's.  (The 8-GPU run is the driver's; RCCL needs one device per rank.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from openhush_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, model_path, n_windows, tail, q):
+    import torch.distributed as dist
+    from openhush_amd import engine as E, shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pcm = np.concatenate([synth.synth_audio(50 + w) for w in range(n_windows - 1)] + [synth.synth_audio(50 + n_windows - 1, tail)])
+    ctx = E.Context.from_file(model_path, 0, E.OHW_DTYPE_BF16)
+    run = shard.engine_window_runner(ctx, 2)
+    res = shard.transcribe_sharded(run, pcm, n_windows, ctx.hp.n_text_ctx, dist, world, rank)
+    dist.barrier()
+    if rank == 0:
+        q.put(res)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_the_single_process_engine(tmp_models):
+    from openhush_amd import engine as E
+    path = tmp_models("micro")
+    n_windows, tail = 5, 200000
+    pcm = np.concatenate([synth.synth_audio(50 + w) for w in range(n_windows - 1)] + [synth.synth_audio(50 + n_windows - 1, tail)])
+    eng = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_BF16, 2)
+    eng.transcribe(E.AudioBuffer(pcm, 16000))
+    ref, lens = eng.last_tokens(), [q[0] for q in eng.last_quality()]
+    eng.close()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, path, n_windows, tail, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [len(t) for t in got] == lens
+    assert [t for w in got for t in w] == ref

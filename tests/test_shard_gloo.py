@@ -59,3 +59,41 @@ def test_assignment_is_a_partition():
         assert seen == list(range(n))
         sizes = [len(shard.assign_windows(n, world, r)) for r in range(world)]
         assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_long(rank, world, port, n_windows, q):
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pcm = np.arange(n_windows * 480000 - 1234, dtype=np.float32)          # the last window is short
+    seen = []
+
+    def fake_engine(windows):          # "tokens" that identify the window by its first sample and its length
+        seen.extend(len(w) for w in windows)
+        return [[int(w[0]) // 480000, len(w) % 50000] for w in windows]
+
+    res = shard.transcribe_sharded(fake_engine, pcm, n_windows, 8, dist, world, rank)
+    dist.barrier()
+    if rank == 0:
+        q.put(res)
+    else:
+        assert res is None
+    dist.destroy_process_group()
+
+
+def test_one_recording_over_two_ranks_returns_windows_in_order():
+    """config #4 in miniature: fixed 30 s cuts of one recording, round-robin over ranks, gathered on rank 0."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_windows, world = 5, 2
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_long, args=(r, world, port, n_windows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    result = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert result == [[w, 480000 % 50000] for w in range(4)] + [[4, (480000 - 1234) % 50000]]
+
