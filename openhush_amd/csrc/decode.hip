@@ -379,18 +379,22 @@ static void dec_gemm_pick(const DecGemmParams& p, hipStream_t s) {
   static const int logits_nt = getenv("OHW_LOGITS_NT") ? atoi(getenv("OHW_LOGITS_NT")) : 2;
   static const int msplit = getenv("OHW_DEC_MSPLIT") ? atoi(getenv("OHW_DEC_MSPLIT")) : 1;
   const int cus = p.cu_budget > 0 ? p.cu_budget : 256;
+  const int mt = (p.M + 15) / 16;          // 16-row m-tiles
   if constexpr (EPI == DEPI_BIAS_RESID && !LN) {
-    // one m-tile per workgroup when that still fits one wave of CUs (and the hand-off path is not in use)
-    if (msplit && p.M > 16 && p.ksplit <= 1 && n_tiles * ((p.M + 15) / 16) <= 2 * cus) { dec_gemm_launch<T, EPI, LN, 1, 1>(p, s); return; }
+    // one m-tile per workgroup when that still fits one wave of CUs (and the hand-off path is not in use); a single
+    // m-tile (batch <= 16) never takes the two-tile kernel, whose second tile would be loaded for nothing
+    if (msplit && p.ksplit <= 1 && (mt == 1 || n_tiles * mt <= 2 * cus)) { dec_gemm_launch<T, EPI, LN, 1, 1>(p, s); return; }
   }
   if constexpr (LN) {
     // one m-tile per workgroup halves the fp32 rows a workgroup normalises; pick the n-tiles per workgroup that keep
     // the grid within one wave of CUs
-    const int mt = (p.M + 15) / 16;
-    if (msplit && p.M > 16 && mt == 2) {
+    if (msplit && mt <= 2) {
       if (n_tiles * mt <= cus) { dec_gemm_launch<T, EPI, LN, 1, 1>(p, s); return; }
-      if ((n_tiles + 1) / 2 * mt <= cus) { dec_gemm_launch<T, EPI, LN, 2, 1>(p, s); return; }
+      if ((n_tiles + 1) / 2 * mt <= cus || mt == 1) { dec_gemm_launch<T, EPI, LN, 2, 1>(p, s); return; }
     }
+  }
+  if constexpr (EPI == DEPI_LOGITS) {
+    if (msplit && mt == 1 && logits_nt == 2) { dec_gemm_launch<T, EPI, LN, 2, 1>(p, s); return; }
   }
   if ((LN && n_tiles > cus) || (EPI == DEPI_LOGITS && logits_nt == 2)) dec_gemm_launch<T, EPI, LN, 2, 2>(p, s);
   else dec_gemm_launch<T, EPI, LN, 1, 2>(p, s);
@@ -495,9 +499,14 @@ constexpr int XA_UNROLL = 4;
 
 template <typename T>
 __global__ __launch_bounds__(XA_THREADS) void cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ xk, const T* __restrict__ xv,
-                                                                T* __restrict__ out, int n_new, int n_head, int t_len) {
+                                                                T* __restrict__ out, int n_new, int n_head, int t_len,
+                                                                float* __restrict__ partials, unsigned* __restrict__ tickets) {
+  // gridDim.z > 1 (small batches: fewer than a wave of (row, head) pairs): the keys of one (row, head) are cut into
+  // gridDim.z contiguous slices on as many CUs - one CU pulls only ~25 GB/s of a 384 KB stream; each slice publishes
+  // its (max, sum, 64-vector) state, the workgroup that draws the last ticket merges them in slice order.
   __shared__ float red_m[4], red_l[4];
   __shared__ float red_o[4][64];
+  __shared__ unsigned s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, m = blockIdx.y;
   const int b = m / n_new;
@@ -517,8 +526,11 @@ __global__ __launch_bounds__(XA_THREADS) void cross_attn_kernel(const T* __restr
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  const int n_groups = (t_len + 7) / 8;
-  for (int g0 = wave; g0 < n_groups; g0 += 4 * XA_UNROLL) {
+  const int n_groups_all = (t_len + 7) / 8;
+  const int per_slice = (n_groups_all + gridDim.z - 1) / gridDim.z;
+  const int g_lo = blockIdx.z * per_slice;
+  const int n_groups = g_lo + per_slice < n_groups_all ? g_lo + per_slice : n_groups_all;
+  for (int g0 = g_lo + wave; g0 < n_groups; g0 += 4 * XA_UNROLL) {
     vec8_t<T> kf[XA_UNROLL], vf[XA_UNROLL];
     int keys[XA_UNROLL];
 #pragma unroll
@@ -571,23 +583,69 @@ __global__ __launch_bounds__(XA_THREADS) void cross_attn_kernel(const T* __restr
     if (part == 0) { red_m[wave] = mrun; red_l[wave] = lrun; }
   }
   __syncthreads();
+  float mn = 0.f, l = 0.f, o = 0.f;
   if (tid < 64) {
-    float mn = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
-    float l = 0.f, o = 0.f;
+    mn = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float a = red_m[w] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(red_m[w] - mn);
       l += red_l[w] * a;
       o += red_o[w][tid] * a;
     }
-    out[act_tiled_offset(m, h * 64 + tid, d)] = (T)(o / l);
   }
+  if (gridDim.z > 1) {
+    // publish {o[64], max, sum} of this slice (wave 0 only holds it), ticket, last arriver merges in slice order
+    const int KS = gridDim.z;
+    unsigned* slot = (unsigned*)partials + (((int64_t)m * n_head + h) * KS + blockIdx.z) * 68;
+    if (tid < 64) {
+      __hip_atomic_store(slot + tid, __float_as_uint(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) {
+        __hip_atomic_store(slot + 64, __float_as_uint(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 65, __float_as_uint(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid == 0) s_ticket = __hip_atomic_fetch_add(tickets + m * n_head + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_ticket != (unsigned)KS - 1 || tid >= 64) return;
+    if (tid == 0) __hip_atomic_store(tickets + m * n_head + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every load of the merge is issued before the first is used (sc1 buffer loads; a chain of waited atomic loads
+    // would be 3 * KS dependent round trips)
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(partials + ((int64_t)m * n_head + h) * KS * 68), 0, KS * 68 * 4, 0x00020000);
+    float mk[XA_MAX_SPLIT], lk[XA_MAX_SPLIT], ok[XA_MAX_SPLIT];
+#pragma unroll
+    for (int k = 0; k < XA_MAX_SPLIT; ++k) {
+      const int kk = k < KS ? k : 0;
+      mk[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (kk * 68 + 64) * 4, 0, 16));
+      lk[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (kk * 68 + 65) * 4, 0, 16));
+      ok[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (kk * 68 + tid) * 4, 0, 16));
+    }
+    float mm = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < XA_MAX_SPLIT; ++k) if (k < KS) mm = fmaxf(mm, mk[k]);
+    l = 0.f; o = 0.f;
+#pragma unroll
+    for (int k = 0; k < XA_MAX_SPLIT; ++k) {
+      if (k < KS) {
+        const float a = mk[k] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mk[k] - mm);
+        l += lk[k] * a;
+        o += ok[k] * a;
+      }
+    }
+  }
+  if (tid < 64) out[act_tiled_offset(m, h * 64 + tid, d)] = (T)(o / l);
   TRACE(3, 3);
 }
 template <typename T>
-void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out, int M, int n_new, int n_head, int t_len, hipStream_t s) {
-  hipLaunchKernelGGL((cross_attn_kernel<T>), dim3(n_head, M), dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_new,
-                     n_head, t_len);
+void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out, int M, int n_new, int n_head, int t_len, float* partials,
+                       unsigned* tickets, int max_split_rows, hipStream_t s) {
+  // fewer (row, head) pairs than two per CU: cut the keys (at most 8 slices, each at least a few hundred keys)
+  int ks = 1;
+  if (partials && tickets && M <= max_split_rows) {
+    while (ks < XA_MAX_SPLIT && (int64_t)M * n_head * ks < 512 && t_len / (ks * 2) >= 64) ks *= 2;
+  }
+  hipLaunchKernelGGL((cross_attn_kernel<T>), dim3(n_head, M, ks), dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_new,
+                     n_head, t_len, partials, tickets);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -754,7 +812,7 @@ void launch_sampler(const SamplerParams& p, hipStream_t s) {
   template void launch_dec_gemm<T>(const DecGemmParams&, int, hipStream_t); \
   template void launch_embed<T>(const void*, const float*, const int32_t*, const int32_t*, float*, int, int, int, hipStream_t); \
   template void launch_self_attn<T>(const void*, const void*, const void*, const int32_t*, void*, int, int, int, int, hipStream_t); \
-  template void launch_cross_attn<T>(const void*, const void*, const void*, void*, int, int, int, int, hipStream_t);
+  template void launch_cross_attn<T>(const void*, const void*, const void*, void*, int, int, int, int, float*, unsigned*, int, hipStream_t);
 INST(bf16_t)
 INST(f16_t)
 #undef INST

@@ -79,6 +79,8 @@ struct ohw_state {
   int ksplit_long = 1, ksplit_short = 1;
   int stream_cus = 0;            // CUs of the current stream's mask (0 = unrestricted)
   DevBuf samp_part, samp_ticket;   // sampler: per-slice partial states and arrival tickets
+  DevBuf xa_part, xa_ticket;       // cross-attention over key slices (small batches)
+  int xa_rows = 0;
   DevBuf step_tok, n_past, tokens, n_cur, next_tok, done, n_done, sum_lp;
   int m_max = 0;
   int64_t logits_ld = 0;
@@ -166,6 +168,9 @@ void state_alloc(ohw_state* st) {
     st->ks_ticket.alloc(tiles * 4, true);
     st->samp_part.alloc((size_t)B * SAMPLER_SPLIT * 8 * 4, true);
     st->samp_ticket.alloc((size_t)B * 4, true);
+    st->xa_rows = std::min(st->m_max, 24);       // 24 rows x 20 heads is already two (row, head) pairs per CU
+    st->xa_part.alloc((size_t)st->xa_rows * H * XA_MAX_SPLIT * 68 * 4, true);
+    st->xa_ticket.alloc((size_t)st->xa_rows * H * 4, true);
     st->ksplit_long = dec_ksplit_long();
     st->ksplit_short = dec_ksplit_short();
   }
@@ -303,7 +308,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
     {
       ProfScope psx(st, OHW_PROF_DEC_XATTN, 2.0 * 2.0 * (double)M * H * Tn * 64.0);
       launch_cross_attn<T>(st->dq.p, (const T*)st->xkv.p + (int64_t)(2 * l) * xkv_slab, (const T*)st->xkv.p + (int64_t)(2 * l + 1) * xkv_slab,
-                           st->da.p, M, n_new, H, Tn, s);
+                           st->da.p, M, n_new, H, Tn, st->xa_part.as<float>(), st->xa_ticket.as<unsigned>(), st->xa_rows, s);
     }
     gemm(st->da.p, nullptr, w.wxo, w.bxo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
     gemm(st->dx.p, &w.ln2, w.w1, w.b1, st->df.p, 4 * d, d, DEPI_BIAS_GELU_T, 4 * d);

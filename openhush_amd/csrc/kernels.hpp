@@ -75,8 +75,11 @@ template <typename T> void launch_embed(const void* emb_tiled, const float* pos,
 template <typename T> void launch_self_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* n_past,
                                             void* out, int M, int n_new, int n_head, int n_ctx, hipStream_t s);
 // cross-attention: q T [M][d]; cross K/V head-major T [B][H][t_len][64] of this layer -> out T, activation-tile order
+// partials / tickets (may be null): scratch for cutting the keys of a (row, head) over up to XA_MAX_SPLIT workgroups when
+// M <= max_split_rows leaves most CUs idle: f32 [max_split_rows][n_head][XA_MAX_SPLIT][68], u32 [max_split_rows][n_head] (zero)
+constexpr int XA_MAX_SPLIT = 8;
 template <typename T> void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out, int M, int n_new,
-                                             int n_head, int t_len, hipStream_t s);
+                                             int n_head, int t_len, float* partials, unsigned* tickets, int max_split_rows, hipStream_t s);
 
 // device-side logits filter + arg-max (restates oracle ref_process_logits)
 struct SamplerParams {
