@@ -190,6 +190,57 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   float bias[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) bias[j] = p.bias ? p.bias[nb + j] : 0.0f;
+  if constexpr (EPI == EPI_BIAS_RESID_F32) {
+    // fp32 residual read-modify-write through LDS.  In the MFMA layout a lane owns 64 B of a row and a wave-instruction
+    // touches 16 rows x 4 x 16 B: 32 half-used cache lines per instruction - a tile's 512 KB of residual traffic took
+    // ~35 us that way (the K = 1280 out-projection ran at half the rate of the same shape with a 16-bit store).  The
+    // finished tile goes to the (now free) LDS, 128 rows at a time, chunk-swizzled by row, and every wave then walks
+    // whole rows: 64 lanes x 16 B = one 1-KiB row of the tile = 8 full lines per instruction.
+    __syncthreads();                       // every wave is past its last fragment read; no DMA is outstanding
+    float* outf = (float*)p.out;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      if (wm == half) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          const int row = mi * 16 + fr;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const int chunk = (wn * 16 + fq * 4 + ni) ^ (row & 15);
+            f32x4 v4 = acc[mi][ni];
+            v4.x += bias[4 * ni]; v4.y += bias[4 * ni + 1]; v4.z += bias[4 * ni + 2]; v4.w += bias[4 * ni + 3];
+            *(f32x4*)(smem + row * 1024 + chunk * 16) = v4;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i0 = 0; i0 < 16; i0 += 8) {
+        f32x4 old[8];
+        float* optr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          int64_t m = m0 + half * 128 + wave * 16 + i0 + i;
+          if (m > p.M - 1) m = p.M - 1;               // unconditional loads (clamped row), masked stores
+          int64_t b = 0, rr = m;
+          if (p.rows_per_batch < p.M) { const unsigned bb = (unsigned)m / (unsigned)p.rows_per_batch; b = bb; rr = m - (int64_t)bb * p.rows_per_batch; }
+          optr[i] = outf + b * p.c_batch_stride + rr * p.ldc + n0 + lane * 4;
+          old[i] = *(const f32x4*)optr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = wave * 16 + i0 + i;
+          if (m0 + half * 128 + r >= p.M) continue;
+          const f32x4 v4 = *(const f32x4*)(smem + r * 1024 + ((lane ^ (r & 15)) << 4));
+          f32x4 o4 = old[i];
+          o4.x += v4.x; o4.y += v4.y; o4.z += v4.z; o4.w += v4.w;
+          *(f32x4*)optr[i] = o4;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
     const int64_t m = m0 + wm * 128 + mi * 16 + fr;
