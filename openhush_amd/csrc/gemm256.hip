@@ -6,16 +6,17 @@
 // Structure (after cdna_hip_programming.md section 5, "Pipelining across barriers" / the 8-phase idea):
 //   * 512 threads = 8 waves (2 along m x 4 along n), each wave a 128x64 output tile = 8x4 MFMA tiles of
 //     16x16x32 (128 accumulator VGPRs); one workgroup per CU.
-//   * LDS: ONE 128-KiB array = 2 stages x 2 k-halves x (256x32 A + 256x32 W) x 2 B.  A k-half buffer has
-//     64-byte rows; its four 16-byte chunks are XOR-swizzled with key[(row >> 2) & 3], key = {0,3,2,1},
-//     which makes every ds_read_b128 fragment read conflict-free (bank analysis in DESIGN.md section 5).
-//     Buffers are filled by global_load_lds_dwordx4 (1 KiB = 16 rows per wave-instruction): the LDS
-//     destination is lane-linear, so the swizzle goes on the per-lane SOURCE address and on the read.
+//   * LDS: ONE 128-KiB array = 2 stages x (256 x 64 A + 256 x 64 W) x 2 B.  Rows are 128 B = one whole cache line of
+//     the operand: a global_load_lds_dwordx4 wave-instruction brings 8 rows x 128 B (the first version staged k-halves
+//     with 64-byte rows, i.e. every line was fetched in two half-used pieces by two different instructions).  The eight
+//     16-byte chunks of a row are XOR-swizzled with (row >> 1) & 7, which makes every ds_read_b128 fragment read
+//     conflict-free; the LDS destination of the DMA is lane-linear, so the swizzle goes on the per-lane SOURCE
+//     address and on the read.
 //   * a K-tile is consumed in two phases (k 0..31, then k 32..63), 32 MFMAs per wave each.  The two waves of
 //     a SIMD are staggered by one barrier interval: one reads its fragments for the next phase while the
-//     other runs MFMAs on fragments already in registers.  The refill of a buffer is issued right after the
-//     barrier that retired its last readers and stays in flight for three phase-times behind a counted
-//     s_waitcnt vmcnt(8) + raw s_barrier (a __syncthreads() would drain vmcnt to 0).
+//     other runs MFMAs on fragments already in registers.  A stage is refilled (8 DMA instructions per wave) in each
+//     wave's first read interval after the barrier that retired the stage's last readers; the data is needed two
+//     phase-times later, behind s_waitcnt vmcnt(0) (nothing younger is in flight at that point) + raw s_barrier.
 // Roofline: MFMA.
 #include <cstdlib>
 
@@ -26,10 +27,10 @@ namespace ohw {
 
 constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
 constexpr int G2_THREADS = 512;
-constexpr int G2_HALF = 32768;    // bytes per (stage, k-half): A 16 KiB | W 16 KiB
-constexpr int G2_STAGE = 2 * G2_HALF;
+constexpr int G2_STAGE = 65536;   // bytes per stage: A 256 rows x 128 B | W 256 rows x 128 B
+constexpr int G2_WOFF = 32768;
 
-__device__ __forceinline__ int g2_key(int row) { return (0x6C >> (((row >> 2) & 3) * 2)) & 3; }  // {0,3,2,1}
+__device__ __forceinline__ int g2_key(int row) { return (row >> 1) & 7; }
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
@@ -58,15 +59,14 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   const T* __restrict__ A = (const T*)p.A;
   const T* __restrict__ W = (const T*)p.W;
 
-  // ---- staging: per k-half buffer each operand is 16 blocks of 1 KiB (16 rows x 64 B); wave w fills
-  // blocks 2w and 2w+1.  lane -> row r = lane>>2 of the block, LDS chunk c = lane&3, holding data chunk
-  // c ^ key(row).
-  const int sr = lane >> 2, sc = lane & 3;
-  const T* a_src[2];
-  const T* w_src[2];
+  // ---- staging: per stage each operand is 32 blocks of 1 KiB (8 rows x 128 B); wave w fills blocks 4w .. 4w+3.
+  // lane -> row r = lane>>3 of the block, LDS chunk c = lane&7, holding data chunk c ^ key(row).
+  const int sr = lane >> 3, sc = lane & 7;
+  const T* a_src[4];
+  const T* w_src[4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int R = (wave * 2 + j) * 16 + sr;         // LDS row 0..255
+  for (int j = 0; j < 4; ++j) {
+    const int R = (wave * 4 + j) * 8 + sr;          // LDS row 0..255
     const int dchunk = sc ^ g2_key(R);
     int64_t m = m0 + R;
     if (m > p.M - 1) m = p.M - 1;
@@ -80,16 +80,18 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   }
   const int KT = (int)(p.K / G2_BK);
 
-  // one glds of tile kt / k-half h: q = 0,1 -> A blocks, q = 2,3 -> W blocks
-  auto issue1 = [&](int kt, int h, int q) {
-    const int koff = kt * G2_BK + h * 32;
-    const int buf = (kt & 1) * G2_STAGE + h * G2_HALF;
-    if (q < 2)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[q] + koff),
-                                       (__attribute__((address_space(3))) void*)(smem + buf + (wave * 2 + q) * 1024), 16, 0, 0);
-    else
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[q - 2] + koff),
-                                       (__attribute__((address_space(3))) void*)(smem + buf + 16384 + (wave * 2 + (q - 2)) * 1024), 16, 0, 0);
+  // the 8 DMA instructions of this wave for K-tile kt
+  auto issue_tile = [&](int kt) {
+    const int koff = kt * G2_BK;
+    const int buf = (kt & 1) * G2_STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + koff),
+                                       (__attribute__((address_space(3))) void*)(smem + buf + (wave * 4 + j) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + koff),
+                                       (__attribute__((address_space(3))) void*)(smem + buf + G2_WOFF + (wave * 4 + j) * 1024), 16, 0, 0);
   };
 
   f32x4 acc[8][4];
@@ -98,41 +100,35 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // fragment read offsets inside a k-half buffer: row = tile row + (lane & 15), chunk (lane >> 4) ^ key(row);
+  // fragment read offsets inside a stage: row = tile row + (lane & 15), chunk (4h + (lane >> 4)) ^ key(row);
   // tile rows start at multiples of 16, so key(row) depends on (lane & 15) only
   const int fr = lane & 15, fq = lane >> 4;
-  const int fch = (fq ^ g2_key(fr)) << 4;
-  const int a_rd = (wm * 128 + fr) * 64 + fch;
-  const int w_rd = 16384 + (wn * 64 + fr) * 64 + fch;
+  const int fkey = g2_key(fr);
+  const int a_row = (wm * 128 + fr) * 128;
+  const int w_row = G2_WOFF + (wn * 64 + fr) * 128;
 
-  // A "phase" P = 2*kt + h consumes k-half h of K-tile kt (32 MFMAs per wave) from buffer P & 3, filled by
-  // glds group G(P) (4 wave-instructions per thread).
+  // A "phase" P = 2*kt + h consumes k-half h of K-tile kt (32 MFMAs per wave) from stage kt & 1.
   //
   // The two waves that share a SIMD (wave w and w + 4, i.e. wm = 0 / 1) run the SAME program shifted by one
   // barrier interval: in every interval one of them issues its 12 fragment reads for the next phase while
   // the other runs the 32 MFMAs of the fragments it read one interval earlier, so the MFMA pipe of a SIMD
   // always has a wave with operands in registers (MI355X_MICROARCH.md "Two waves per SIMD", item 9):
   //     interval i, wave group g (0/1), j = i - g:   j even -> read phase j/2      j odd -> compute phase j/2
-  // Buffer P & 3 is read in intervals 2P (group 0) and 2P + 1 (group 1) and refilled with G(P + 4): each wave
-  // issues its share in its own next READ interval (2P + 2 for group 0, 2P + 3 for group 1), never while it
-  // computes; the data is needed again in interval 2P + 8: the DMA has 2.5-3 phase-times to land, behind a
-  // counted vmcnt(8) (two younger groups stay in flight).
+  // Stage kt & 1 is last read in phase 2kt + 1 (intervals 4kt + 2 and 4kt + 3) and refilled with tile kt + 2: each wave
+  // issues its share in its read interval of phase 2kt + 2 (4kt + 4 for group 0, 4kt + 5 for group 1), never while it
+  // computes; the data is first read in interval 4kt + 8, behind vmcnt(0) at the barrier that opens it (each wave's
+  // youngest DMA group at that point is that tile's).
   const int NP = 2 * KT;
-  auto issue_group = [&](int P) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) issue1(P >> 1, P & 1, q);
-  };
-  issue_group(0);
-  if (NP > 1) issue_group(1);
-  if (NP > 2) issue_group(2);
+  issue_tile(0);
 
   vec8 fw[4], fa[8];
   auto read_frags = [&](int P) {
-    const int cur = (P & 3) * G2_HALF;
+    const int cur = ((P >> 1) & 1) * G2_STAGE;
+    const int ch = (((P & 1) * 4 + fq) ^ fkey) << 4;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) fw[ni] = *(const vec8*)(smem + cur + w_rd + ni * 1024);
+    for (int ni = 0; ni < 4; ++ni) fw[ni] = *(const vec8*)(smem + cur + w_row + ch + ni * 2048);
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) fa[mi] = *(const vec8*)(smem + cur + a_rd + mi * 1024);
+    for (int mi = 0; mi < 8; ++mi) fa[mi] = *(const vec8*)(smem + cur + a_row + ch + mi * 2048);
   };
   auto compute = [&]() {
     __builtin_amdgcn_s_setprio(1);
@@ -142,14 +138,9 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Ops::mfma16(fw[ni], fa[mi], acc[mi][ni]);
     __builtin_amdgcn_s_setprio(0);
   };
-  // barrier that opens an EVEN interval 2*Pn: every wave's share of G(Pn) must have landed (each wave has
-  // exactly two younger groups in flight at this point, whichever group it belongs to)
-  auto open_even = [&](int Pn) {   // (the refill itself is issued by each wave in its own READ interval)
-    if (Pn < NP) {
-      if (Pn + 2 < NP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (Pn + 1 < NP) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+  // barrier that opens an EVEN interval 2*Pn: when Pn starts a K-tile, every wave's share of that tile must have landed
+  auto open_even = [&](int Pn) {
+    if (Pn < NP && (Pn & 1) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -164,7 +155,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
     for (int P = 0; P < NP; ++P) {
       open_even(P);
       read_frags(P);
-      if (P + 3 < NP) issue_group(P + 3);   // buffer of phase P - 1: its readers are behind the barrier above
+      if ((P & 1) == 0 && (P >> 1) + 1 < KT) issue_tile((P >> 1) + 1);   // the other stage: its readers are behind the barrier above
       __builtin_amdgcn_sched_barrier(0);
       open_odd();
       compute();
@@ -177,7 +168,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
     for (int P = 0; P < NP; ++P) {
       open_odd();
       read_frags(P);
-      if (P + 3 < NP) issue_group(P + 3);   // this wave's share, one interval after the partner group's
+      if ((P & 1) == 0 && (P >> 1) + 1 < KT) issue_tile((P >> 1) + 1);   // this wave's share, one interval after the partner group's
       __builtin_amdgcn_sched_barrier(0);
       open_even(P + 1);
       compute();
