@@ -285,9 +285,6 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
                   : epi == DEPI_LOGITS ? OHW_PROF_DEC_GEMM_LOGITS : OHW_PROF_DEC_GEMM;
     ProfScope ps(st, cls, 2.0 * ((double)((N + 15) / 16 * 16) * K) * ((M + 31) / 32));
     launch_dec_gemm<T>(p, epi, s);
-#ifdef OHW_EXP_DOUBLE
-    launch_dec_gemm<T>(p, epi, s);   // timing experiment only (instrumented build): the same launch again, everything warm
-#endif
   };
   for (int l = 0; l < L; ++l) {
     const DecLayerW& w = c->dec[l];
