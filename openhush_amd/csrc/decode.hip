@@ -500,7 +500,8 @@ constexpr int XA_UNROLL = 4;
 template <typename T>
 __global__ __launch_bounds__(XA_THREADS) void cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ xk, const T* __restrict__ xv,
                                                                 T* __restrict__ out, int n_new, int n_head, int t_len,
-                                                                float* __restrict__ partials, unsigned* __restrict__ tickets) {
+                                                                float* __restrict__ partials, unsigned* __restrict__ tickets,
+                                                                const int32_t* __restrict__ done) {
   // gridDim.z > 1 (small batches: fewer than a wave of (row, head) pairs): the keys of one (row, head) are cut into
   // gridDim.z contiguous slices on as many CUs - one CU pulls only ~25 GB/s of a 384 KB stream; each slice publishes
   // its (max, sum, 64-vector) state, the workgroup that draws the last ticket merges them in slice order.
@@ -510,6 +511,9 @@ __global__ __launch_bounds__(XA_THREADS) void cross_attn_kernel(const T* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, m = blockIdx.y;
   const int b = m / n_new;
+  // a window that has produced its end-of-text token still rides along in the batch: its rows are computed by the GEMMs
+  // (free) but its 7.7 MB of cross K/V per layer are not streamed (its output row is never used again)
+  if (done && done[b]) return;
   const int d = n_head * 64;
   const int part = lane & 7, slot = lane >> 3;
   const float sc = 0.125f * 1.44269504088896340736f;
@@ -638,14 +642,14 @@ __global__ __launch_bounds__(XA_THREADS) void cross_attn_kernel(const T* __restr
 }
 template <typename T>
 void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out, int M, int n_new, int n_head, int t_len, float* partials,
-                       unsigned* tickets, int max_split_rows, hipStream_t s) {
+                       unsigned* tickets, int max_split_rows, const int32_t* done, hipStream_t s) {
   // fewer (row, head) pairs than two per CU: cut the keys (at most 8 slices, each at least a few hundred keys)
   int ks = 1;
   if (partials && tickets && M <= max_split_rows) {
     while (ks < XA_MAX_SPLIT && (int64_t)M * n_head * ks < 512 && t_len / (ks * 2) >= 64) ks *= 2;
   }
   hipLaunchKernelGGL((cross_attn_kernel<T>), dim3(n_head, M, ks), dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_new,
-                     n_head, t_len, partials, tickets);
+                     n_head, t_len, partials, tickets, done);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -812,7 +816,7 @@ void launch_sampler(const SamplerParams& p, hipStream_t s) {
   template void launch_dec_gemm<T>(const DecGemmParams&, int, hipStream_t); \
   template void launch_embed<T>(const void*, const float*, const int32_t*, const int32_t*, float*, int, int, int, hipStream_t); \
   template void launch_self_attn<T>(const void*, const void*, const void*, const int32_t*, void*, int, int, int, int, hipStream_t); \
-  template void launch_cross_attn<T>(const void*, const void*, const void*, void*, int, int, int, int, float*, unsigned*, int, hipStream_t);
+  template void launch_cross_attn<T>(const void*, const void*, const void*, void*, int, int, int, int, float*, unsigned*, int, const int32_t*, hipStream_t);
 INST(bf16_t)
 INST(f16_t)
 #undef INST

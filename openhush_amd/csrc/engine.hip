@@ -78,6 +78,7 @@ struct ohw_state {
   DevBuf ks_slab, ks_ticket;   // split-K partial tiles and arrival tickets of the decoder's RESID GEMMs
   int ksplit_long = 1, ksplit_short = 1;
   int stream_cus = 0;            // CUs of the current stream's mask (0 = unrestricted)
+  bool skip_done = false;        // inside ohw_greedy: cross-attention skips windows whose done flag is set
   DevBuf samp_part, samp_ticket;   // sampler: per-slice partial states and arrival tickets
   DevBuf xa_part, xa_ticket;       // cross-attention over key slices (small batches)
   int xa_rows = 0;
@@ -305,7 +306,8 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
     {
       ProfScope psx(st, OHW_PROF_DEC_XATTN, 2.0 * 2.0 * (double)M * H * Tn * 64.0);
       launch_cross_attn<T>(st->dq.p, (const T*)st->xkv.p + (int64_t)(2 * l) * xkv_slab, (const T*)st->xkv.p + (int64_t)(2 * l + 1) * xkv_slab,
-                           st->da.p, M, n_new, H, Tn, st->xa_part.as<float>(), st->xa_ticket.as<unsigned>(), st->xa_rows, s);
+                           st->da.p, M, n_new, H, Tn, st->xa_part.as<float>(), st->xa_ticket.as<unsigned>(), st->xa_rows,
+                           st->skip_done ? st->done.as<int32_t>() : nullptr, s);
     }
     gemm(st->da.p, nullptr, w.wxo, w.bxo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
     gemm(st->dx.p, &w.ln2, w.w1, w.b1, st->df.p, 4 * d, d, DEPI_BIAS_GELU_T, 4 * d);
@@ -600,6 +602,7 @@ int ohw_greedy(ohw_state* st, const ohw_sample_params* sp, int batch, int32_t* t
     if (eff.force_len > 0) eff.force_len = n_max;
     fill_sampler(st, &eff, batch, &spar);
     int steps = 0;
+    struct SkipDone { bool& f; explicit SkipDone(bool& r) : f(r) { f = true; } ~SkipDone() { f = false; } } skip_done(st->skip_done);
     Dispatch::run(c->dtype, [&](auto* tag) {
       using T = std::remove_pointer_t<decltype(tag)>;
       run_decoder_step<T>(st, batch, n_prompt);

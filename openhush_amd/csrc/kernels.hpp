@@ -79,7 +79,8 @@ template <typename T> void launch_self_attn(const void* q, const void* k_cache, 
 // M <= max_split_rows leaves most CUs idle: f32 [max_split_rows][n_head][XA_MAX_SPLIT][68], u32 [max_split_rows][n_head] (zero)
 constexpr int XA_MAX_SPLIT = 8;
 template <typename T> void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out, int M, int n_new,
-                                             int n_head, int t_len, float* partials, unsigned* tickets, int max_split_rows, hipStream_t s);
+                                             int n_head, int t_len, float* partials, unsigned* tickets, int max_split_rows,
+                                             const int32_t* done /* [B] or null: windows whose rows are skipped */, hipStream_t s);
 
 // device-side logits filter + arg-max (restates oracle ref_process_logits)
 struct SamplerParams {
