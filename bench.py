@@ -81,7 +81,22 @@ def main():
     hp = synth.PRESETS[args.model]
     dtype = E.OHW_DTYPE_BF16 if args.dtype == "bf16" else E.OHW_DTYPE_F16
     B = args.batch
-    ctx = E.Context.synthetic(hp.as_list(), 1234, local_rank, dtype)
+    if use_dist:
+        # the multi-GPU load path: rank 0 makes the model (here: procedural weights; in production: reads the ggml file),
+        # its resident weight blob (3.1 GB) goes to the other ranks in ONE RCCL broadcast over xGMI, they import it into a
+        # shell context (include/ohw.h, ohw_ctx_blob_*; shard.load_model_broadcast does the same from a file).  Not timed.
+        ctx = E.Context.synthetic(hp.as_list(), 1234, local_rank, dtype) if rank == 0 else E.Context.shell(hp.as_list(), local_rank, dtype)
+        nblob = ctx.blob_size()
+        blob = torch.empty(nblob, dtype=torch.uint8, device=torch.device("cuda", local_rank))
+        if rank == 0:
+            ctx.export_blob(blob.data_ptr(), nblob)
+        dist.broadcast(blob, src=0)
+        torch.cuda.synchronize()
+        if rank != 0:
+            ctx.import_blob(blob.data_ptr(), nblob)
+        del blob
+    else:
+        ctx = E.Context.synthetic(hp.as_list(), 1234, local_rank, dtype)
     # the batch may be split over several concurrent states (each with its own HIP stream): the
     # latency-bound decoder kernels of one sub-batch then overlap the HBM-bound ones of another
     S = max(1, args.streams)

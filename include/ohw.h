@@ -82,6 +82,14 @@ int ohw_ctx_create(const char* model_path, int device, int dtype, ohw_ctx** out)
 /* procedural weights generated on the device (tests / bench; openhush_amd/synth.py is the spec)  */
 int ohw_ctx_create_synthetic(const ohw_hparams* hp, uint32_t seed, int device, int dtype, ohw_ctx** out);
 int ohw_ctx_info(const ohw_ctx* ctx, ohw_hparams* hp, ohw_special_tokens* tok);
+/* ---- a loaded model as ONE device blob: the rank that read the file exports it, the caller broadcasts it (RCCL) and
+ *      the other ranks import it into a shell context made from the same hparams and dtype - instead of every rank
+ *      reading and repacking the file ("one ncclBroadcast of the packed weight blob at load").  A shell has
+ *      no vocabulary strings: the exporting rank detokenises. ------------------------------------------------------ */
+int ohw_ctx_create_shell(const ohw_hparams* hp, int device, int dtype, ohw_ctx** out);
+size_t ohw_ctx_blob_size(const ohw_ctx* ctx);
+int ohw_ctx_blob_export(const ohw_ctx* ctx, void* dst_device, size_t capacity);
+int ohw_ctx_blob_import(ohw_ctx* ctx, const void* src_device, size_t bytes);
 /* bytes of token `id` (text tokens only); returns length, 0 for specials                         */
 int ohw_token_text(const ohw_ctx* ctx, int32_t id, const char** text);
 void ohw_ctx_free(ohw_ctx* ctx); /* WhisperContext drop */

@@ -67,7 +67,8 @@ def _transcribe_ranks(args, audio) -> int:
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     E.validate_audio(audio.samples, audio.sample_rate)
-    ctx = E.Context.from_file(args.model_path, local, E.OHW_DTYPE_BF16 if args.dtype == "bf16" else E.OHW_DTYPE_F16)
+    # rank 0 reads the file, the packed weights reach the other GPUs in one RCCL broadcast
+    ctx = shard.load_model_broadcast(args.model_path, dist, world, rank, local, E.OHW_DTYPE_BF16 if args.dtype == "bf16" else E.OHW_DTYPE_F16)
     p = ctx.default_params()
     if args.language != "auto":
         p.lang_id = E.lang_code_to_id(args.language)

@@ -18,6 +18,7 @@
 namespace ohw {
 ohw_ctx* ctx_from_file(const char* path, int device, int dtype);
 ohw_ctx* ctx_synthetic(const ohw_hparams* hp, uint32_t seed, int device, int dtype);
+ohw_ctx* ctx_shell(const ohw_hparams* hp, int device, int dtype);
 
 thread_local std::string g_last_error;
 
@@ -803,6 +804,40 @@ int ohw_state_fetch(ohw_state* st, const char* what, int batch, float* out, int6
       return;
     }
     throw Error(OHW_E_INVALID_ARG, std::string("fetch: unknown activation '") + what + "'");
+  });
+}
+
+int ohw_ctx_create_shell(const ohw_hparams* hp, int device, int dtype, ohw_ctx** out) {
+  return guard([&] {
+    if (!out) throw Error(OHW_E_INVALID_ARG, "out is null");
+    *out = nullptr;
+    *out = ctx_shell(hp, device, dtype);
+  });
+}
+
+// blob = [weight arena | mel filterbank], each part padded to 256 bytes
+static size_t blob_part(size_t n) { return (n + 255) / 256 * 256; }
+size_t ohw_ctx_blob_size(const ohw_ctx* ctx) { return ctx ? blob_part(ctx->arena.bytes) + blob_part(ctx->mel_filters.bytes) : 0; }
+
+int ohw_ctx_blob_export(const ohw_ctx* ctx, void* dst_device, size_t capacity) {
+  return guard([&] {
+    if (!ctx || !dst_device) throw Error(OHW_E_INVALID_ARG, "null argument");
+    if (capacity < ohw_ctx_blob_size(ctx)) throw Error(OHW_E_INVALID_ARG, "blob_export: destination is smaller than ohw_ctx_blob_size");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipMemcpy(dst_device, ctx->arena.p, ctx->arena.bytes, hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipMemcpy((char*)dst_device + blob_part(ctx->arena.bytes), ctx->mel_filters.p, ctx->mel_filters.bytes, hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipDeviceSynchronize());
+  });
+}
+
+int ohw_ctx_blob_import(ohw_ctx* ctx, const void* src_device, size_t bytes) {
+  return guard([&] {
+    if (!ctx || !src_device) throw Error(OHW_E_INVALID_ARG, "null argument");
+    if (bytes != ohw_ctx_blob_size(ctx)) throw Error(OHW_E_LOAD_FAILED, "blob_import: size does not match this model's layout (hparams / dtype differ?)");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipMemcpy(ctx->arena.p, src_device, ctx->arena.bytes, hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipMemcpy(ctx->mel_filters.p, (const char*)src_device + blob_part(ctx->arena.bytes), ctx->mel_filters.bytes, hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipDeviceSynchronize());
   });
 }
 

@@ -479,4 +479,26 @@ ohw_ctx* ctx_synthetic(const ohw_hparams* hp, uint32_t seed, int device, int dty
   return c.release();
 }
 
+// a context with every buffer allocated and NO weights in it: the receiving end of a weight broadcast
+// (ohw_ctx_blob_import).  Vocabulary: placeholder strings (the rank that loaded the file detokenises).
+ohw_ctx* ctx_shell(const ohw_hparams* hp, int device, int dtype) {
+  if (!hp) throw Error(OHW_E_INVALID_ARG, "hparams is null");
+  if (dtype != OHW_DTYPE_BF16 && dtype != OHW_DTYPE_F16) throw Error(OHW_E_INVALID_ARG, "dtype must be OHW_DTYPE_BF16 or OHW_DTYPE_F16");
+  check_hparams(*hp);
+  std::unique_ptr<ohw_ctx> c(new ohw_ctx());
+  c->hp = *hp;
+  select_device(device);
+  c->device = device;
+  c->dtype = dtype;
+  const int n_text = hp->n_vocab >= 51865 ? 50257 : 50256;
+  c->vocab.assign((size_t)n_text, std::string());
+  set_special_tokens(c.get());
+  upload_front_end(c.get(), slaney_filters(hp->n_mels));   // overwritten by the import
+  hipStream_t s = nullptr;
+  if (dtype == OHW_DTYPE_BF16) { Placer<bf16_t> pl(c.get(), s); pl.allocate(); }
+  else { Placer<f16_t> pl(c.get(), s); pl.allocate(); }
+  HIP_CHECK(hipDeviceSynchronize());
+  return c.release();
+}
+
 }  // namespace ohw

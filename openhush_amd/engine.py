@@ -38,6 +38,9 @@ class HParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_vocab", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
                                          "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer", "n_mels", "ftype")]
 
+    def as_list(self):
+        return [int(getattr(self, n)) for n, _ in self._fields_]
+
 
 class SpecialTokens(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("eot", "sot", "translate", "transcribe", "solm", "prev", "nosp", "no_timestamps",
@@ -72,6 +75,7 @@ EXPORTS = [
     "ohw_engine_ctx", "ohw_lang_id_to_code", "ohw_lang_code_to_id", "ohw_last_error", "ohw_abi_version", "ohw_state_fetch",
     "ohw_dbg_gemm", "ohw_dbg_attention", "ohw_state_profile_begin", "ohw_state_profile_end", "ohw_ctx_weight_digest", "ohw_detect_language", "ohw_state_ctx", "ohw_engine_set_window_mode", "ohw_engine_last_text", "ohw_engine_last_quality",
     "ohw_stream_create", "ohw_stream_destroy", "ohw_stream_wait", "ohw_stream_sync",
+    "ohw_ctx_create_shell", "ohw_ctx_blob_size", "ohw_ctx_blob_export", "ohw_ctx_blob_import",
 ]
 
 
@@ -119,6 +123,11 @@ def lib():
         L.ohw_ctx_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
         L.ohw_ctx_create_synthetic.argtypes = [C.POINTER(HParams), C.c_uint32, C.c_int, C.c_int, C.POINTER(vp)]
         L.ohw_ctx_info.argtypes = [vp, C.POINTER(HParams), C.POINTER(SpecialTokens)]
+        L.ohw_ctx_create_shell.argtypes = [C.POINTER(HParams), C.c_int, C.c_int, C.POINTER(vp)]
+        L.ohw_ctx_blob_size.argtypes = [vp]
+        L.ohw_ctx_blob_size.restype = C.c_size_t
+        L.ohw_ctx_blob_export.argtypes = [vp, vp, C.c_size_t]
+        L.ohw_ctx_blob_import.argtypes = [vp, vp, C.c_size_t]
         L.ohw_token_text.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p)]
         L.ohw_ctx_free.argtypes = [vp]
         L.ohw_ctx_free.restype = None
@@ -236,6 +245,23 @@ class Context:
         h = C.c_void_p()
         _check(lib().ohw_ctx_create_synthetic(C.byref(hp), seed, device, dtype, C.byref(h)))
         return cls(h.value)
+
+    @classmethod
+    def shell(cls, hparams: Sequence[int], device: int = 0, dtype: int = OHW_DTYPE_BF16) -> "Context":
+        """every buffer allocated, no weights: the receiving end of a weight broadcast (import_blob)"""
+        hp = HParams(*[int(x) for x in hparams])
+        h = C.c_void_p()
+        _check(lib().ohw_ctx_create_shell(C.byref(hp), device, dtype, C.byref(h)))
+        return cls(h.value)
+
+    def blob_size(self) -> int:
+        return int(lib().ohw_ctx_blob_size(self.h))
+
+    def export_blob(self, dst_device_ptr: int, capacity: int):
+        _check(lib().ohw_ctx_blob_export(self.h, C.c_void_p(dst_device_ptr), capacity))
+
+    def import_blob(self, src_device_ptr: int, nbytes: int):
+        _check(lib().ohw_ctx_blob_import(self.h, C.c_void_p(src_device_ptr), nbytes))
 
     def default_params(self) -> SampleParams:
         p = SampleParams()

@@ -101,3 +101,38 @@ def engine_window_runner(ctx, max_batch: int, params=None, mel_mode: Optional[in
 
     return run
 
+
+def load_model_broadcast(model_path: str, dist, world: int, rank: int, device_index: int, dtype: int, via_host: bool = False):
+    """Rank 0 reads and repacks the ggml file; its resident weight blob (3.1 GB at large-v3) goes to the other ranks in ONE
+    broadcast (RCCL over xGMI with the nccl backend), which import it into a shell context - instead of `world` file reads
+    (SURVEY.md 8e).  The hyper-parameters travel first (11 ints).  via_host=True stages through host memory (gloo)."""
+    from . import engine as E
+    dev = torch.device("cuda", device_index)
+    hp_t = torch.zeros(11, dtype=torch.int32)
+    ctx = None
+    if rank == 0:
+        ctx = E.Context.from_file(model_path, device_index, dtype)
+        hp_t = torch.tensor(ctx.hp.as_list(), dtype=torch.int32)
+    if world == 1:
+        return ctx
+    hp_t = hp_t if via_host else hp_t.to(dev)
+    dist.broadcast(hp_t, src=0)
+    if rank != 0:
+        ctx = E.Context.shell([int(v) for v in hp_t.cpu()], device_index, dtype)
+    n = ctx.blob_size()
+    blob = torch.empty(n, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        ctx.export_blob(blob.data_ptr(), n)
+    if via_host:
+        host = blob.cpu()
+        dist.broadcast(host, src=0)
+        if rank != 0:
+            blob.copy_(host)
+    else:
+        dist.broadcast(blob, src=0)
+    torch.cuda.synchronize(dev)
+    if rank != 0:
+        ctx.import_blob(blob.data_ptr(), n)
+    del blob
+    return ctx
+

@@ -50,3 +50,43 @@ def test_two_ranks_on_one_gpu_match_the_single_process_engine(tmp_models):
         assert p.exitcode == 0
     assert [len(t) for t in got] == lens
     assert [t for w in got for t in w] == ref
+
+
+def _worker_bcast(rank, world, port, model_path, q):
+    import torch.distributed as dist
+    from openhush_amd import engine as E, shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = shard.load_model_broadcast(model_path, dist, world, rank, 0, E.OHW_DTYPE_BF16, via_host=True)
+    st = E.State(ctx, 1)
+    st.mel(synth.synth_audio(90)[None, :], [480000], E.OHW_MEL_ZERO_TAIL, want=False)
+    st.encode(1)
+    p = ctx.default_params()
+    p.n_max = 16
+    toks, _ = st.greedy(1, p)
+    q.put((rank, ctx.weight_digests(), toks[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_weights_broadcast_from_rank0_equal_the_file(tmp_models):
+    """Only rank 0 reads the model file; rank 1 imports the broadcast blob into a shell context: same resident weights
+    (every buffer's digest), same tokens.  (gloo through host memory here; the nccl path hands RCCL the device blob.)"""
+    path = tmp_models("micro")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bcast, args=(r, 2, port, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r, dig, toks = q.get(timeout=300)
+        got[r] = (dig, toks)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0] and len(got[0][0]) > 20
+    assert got[0][1] == got[1][1] and len(got[0][1]) > 0
+
