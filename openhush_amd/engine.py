@@ -559,3 +559,24 @@ def model_filename(name: str) -> str:
     key = name.lower()
     key = _MODEL_ALIASES.get(key, key)
     return _MODEL_FILES[key]
+
+
+# approximate download sizes the reference shows to the user (src/engine/whisper.rs:82-92)
+_MODEL_SIZES = {"tiny": 75_000_000, "base": 142_000_000, "small": 466_000_000, "medium": 1_500_000_000, "large-v3": 3_000_000_000}
+
+
+def model_size_bytes(name: str) -> int:
+    key = name.lower()
+    return _MODEL_SIZES[_MODEL_ALIASES.get(key, key)]
+
+
+def format_size(n: int) -> str:
+    """reference src/engine/whisper.rs:444-458 (Rust {:.0} / {:.1} formatting: round half to even on the binary value)"""
+    kb, mb, gb = 1024, 1024 ** 2, 1024 ** 3
+    if n >= gb:
+        return f"{n / gb:.1f} GB"
+    if n >= mb:
+        return f"{n / mb:.0f} MB"
+    if n >= kb:
+        return f"{n / kb:.0f} KB"
+    return f"{n} B"

@@ -83,6 +83,16 @@ def test_model_names():
         E.model_filename("tiny.en")     # the reference has no .en models
 
 
+# reference src/engine/whisper.rs tests :786-831 (known answers of the reference's own unit tests)
+def test_model_sizes_and_format_size():
+    assert [E.model_size_bytes(m) for m in ("tiny", "base", "small", "medium", "large-v3")] == \
+        [75_000_000, 142_000_000, 466_000_000, 1_500_000_000, 3_000_000_000]
+    assert E.format_size(500) == "500 B" and E.format_size(1023) == "1023 B"
+    assert E.format_size(1024) == "1 KB" and E.format_size(5120) == "5 KB"
+    assert E.format_size(1024 * 1024) == "1 MB" and E.format_size(75_000_000) == "72 MB" and E.format_size(500 * 1024 * 1024) == "500 MB"
+    assert E.format_size(1024 ** 3) == "1.0 GB" and E.format_size(3_000_000_000) == "2.8 GB"
+
+
 def test_missing_model_is_reported_before_any_device_work(tmp_path):
     # reference src/engine/whisper.rs:141-154 and test :984-997
     with pytest.raises(E.ModelNotFound) as ei:
