@@ -112,7 +112,14 @@ def main(argv=None) -> int:
     args = ap.parse_args(argv)
 
     from . import engine as E
-    audio = E.AudioBuffer(load_wav_file(args.file), SAMPLE_RATE)
+    if not os.path.isfile(args.file):            # reference src/main.rs:985-987 and tests/cli_integration.rs:262-269
+        print(f"error: File not found: {args.file}", file=sys.stderr)
+        return 1
+    try:
+        audio = E.AudioBuffer(load_wav_file(args.file), SAMPLE_RATE)
+    except (ValueError, wave.Error, EOFError) as ex:
+        print(f"error: {ex}", file=sys.stderr)
+        return 1
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         return _transcribe_ranks(args, audio)
     use_gpu = args.device.lower() != "cpu"                    # reference src/main.rs:1037

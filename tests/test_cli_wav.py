@@ -34,6 +34,17 @@ def test_int16_scaling_channel_average_and_min_duration_pad(tmp_path):
         cli.load_wav_file(str(tmp_path / "r.wav"))
 
 
+def test_cli_surface_like_the_reference_cli_tests(tmp_path):
+    """reference tests/cli_integration.rs:252-269: `transcribe --help` lists --model and --format; a missing file fails
+    with 'not found' on stderr (no device is touched on either path)."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    h = subprocess.run([sys.executable, "-m", "openhush_amd.cli", "transcribe", "--help"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert h.returncode == 0 and "--model" in h.stdout and "--format" in h.stdout
+    m = subprocess.run([sys.executable, "-m", "openhush_amd.cli", "transcribe", "nonexistent.wav", "--model-path", str(tmp_path / "ggml-tiny.bin")],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert m.returncode != 0 and ("not found" in m.stderr or "error" in m.stderr)
+
+
 @pytest.mark.gpu
 def test_transcribe_cli_json(tmp_path, tmp_models):
     pcm = synth.synth_audio(5, 160000)                            # the 10 s file of config #1
