@@ -348,7 +348,7 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
         if (rc == OHW_OK) rc = ohw_stream_create(e->device, 0, 0, &e->s_full);
         int total = 0;
         if (rc == OHW_OK && hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) rc = OHW_E_TRANSCRIBE;
-        if (rc == OHW_OK && e->enc_cus >= total) rc = OHW_E_INVALID_ARG;
+        if (rc == OHW_OK && e->enc_cus >= total) e->enc_cus = std::max(1, total * 3 / 8);   // a smaller device: the same 3 : 5 split
         if (rc == OHW_OK) rc = ohw_stream_create(e->device, 0, e->enc_cus, &e->s_enc);
         if (rc == OHW_OK) rc = ohw_stream_create(e->device, e->enc_cus, total - e->enc_cus, &e->s_dec);
         if (rc != OHW_OK) {
