@@ -94,6 +94,29 @@ int ohw_ctx_blob_import(ohw_ctx* ctx, const void* src_device, size_t bytes);
 int ohw_token_text(const ohw_ctx* ctx, int32_t id, const char** text);
 void ohw_ctx_free(ohw_ctx* ctx); /* WhisperContext drop */
 
+/* ---- audio preprocessing, the step right before the path (host code: the envelope follower and the
+ *      limiter are sequential recurrences over the whole recording).  In place, fp32, the reference's operation order:
+ *      AudioBuffer::{rms_db, apply_gain, normalize_rms, compress, limit} (reference src/input/audio.rs:86-239),
+ *      resample_linear (:972-990), TranscriptionWorker::preprocess_audio (src/queue/worker.rs:196-240).  Not built: the
+ *      rubato sinc resampler and RNNoise (third-party crates). ------------------------------------------------------ */
+typedef struct ohw_preprocess_config {
+  int32_t preprocessing;              /* master switch, reference default 0 (src/config.rs:958,984) */
+  int32_t normalization_enabled; float normalization_target_db;                       /* 1, -18 dB */
+  int32_t compression_enabled; float compression_threshold_db, compression_ratio,     /* 1, -24 dB, 4:1, */
+      compression_attack_ms, compression_release_ms, compression_makeup_gain_db;      /* 5 ms, 50 ms, +6 dB */
+  int32_t limiter_enabled; float limiter_ceiling_db, limiter_release_ms;              /* 1, -1 dB, 50 ms */
+} ohw_preprocess_config;
+void ohw_default_preprocess_config(ohw_preprocess_config* c);
+int ohw_preprocess_audio(float* samples, int64_t n, uint32_t sample_rate, const ohw_preprocess_config* c);
+float ohw_dsp_rms_db(const float* samples, int64_t n);                 /* -inf for silence / empty */
+void ohw_dsp_apply_gain(float* samples, int64_t n, float gain_db);
+void ohw_dsp_normalize_rms(float* samples, int64_t n, float target_db);
+void ohw_dsp_compress(float* samples, int64_t n, uint32_t sample_rate, float threshold_db, float ratio, float attack_ms,
+                      float release_ms, float makeup_gain_db);
+int64_t ohw_dsp_limit(float* samples, int64_t n, uint32_t sample_rate, float ceiling_db, float release_ms); /* samples over the ceiling */
+/* returns the output length; with out == NULL or out_cap too small nothing is written (size query) */
+int64_t ohw_dsp_resample_linear(const float* in, int64_t n, uint32_t from_rate, uint32_t to_rate, float* out, int64_t out_cap);
+
 /* ---- state: replaces ctx.create_state() (reference src/engine/whisper.rs:167-169) ------------- */
 /* max_batch = number of independent 30 s windows processed together (the reference: 1)           */
 int ohw_state_create(ohw_ctx* ctx, int max_batch, ohw_state** out);

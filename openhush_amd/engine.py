@@ -56,6 +56,14 @@ class SampleParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("lang_id", "translate", "no_timestamps", "suppress_blank", "max_initial_ts", "n_max", "force_len")]
 
 
+class PreprocessConfig(C.Structure):
+    """ohw_preprocess_config: the reference's [audio] preprocessing settings (src/config.rs:1020-1070, defaults :1129-1160)"""
+    _fields_ = [("preprocessing", C.c_int32), ("normalization_enabled", C.c_int32), ("normalization_target_db", C.c_float),
+                ("compression_enabled", C.c_int32), ("compression_threshold_db", C.c_float), ("compression_ratio", C.c_float),
+                ("compression_attack_ms", C.c_float), ("compression_release_ms", C.c_float), ("compression_makeup_gain_db", C.c_float),
+                ("limiter_enabled", C.c_int32), ("limiter_ceiling_db", C.c_float), ("limiter_release_ms", C.c_float)]
+
+
 class WindowQuality(C.Structure):
     _fields_ = [("n_tokens", C.c_int32), ("avg_logprob", C.c_float), ("entropy", C.c_float), ("would_fallback", C.c_int32)]
 
@@ -76,6 +84,8 @@ EXPORTS = [
     "ohw_dbg_gemm", "ohw_dbg_attention", "ohw_state_profile_begin", "ohw_state_profile_end", "ohw_ctx_weight_digest", "ohw_detect_language", "ohw_state_ctx", "ohw_engine_set_window_mode", "ohw_engine_last_text", "ohw_engine_last_quality",
     "ohw_stream_create", "ohw_stream_destroy", "ohw_stream_wait", "ohw_stream_sync",
     "ohw_ctx_create_shell", "ohw_ctx_blob_size", "ohw_ctx_blob_export", "ohw_ctx_blob_import",
+    "ohw_default_preprocess_config", "ohw_preprocess_audio", "ohw_dsp_rms_db", "ohw_dsp_apply_gain", "ohw_dsp_normalize_rms",
+    "ohw_dsp_compress", "ohw_dsp_limit", "ohw_dsp_resample_linear",
 ]
 
 
@@ -135,6 +145,21 @@ def lib():
         L.ohw_state_free.argtypes = [vp]
         L.ohw_state_free.restype = None
         L.ohw_state_set_stream.argtypes = [vp, vp]
+        L.ohw_default_preprocess_config.argtypes = [C.POINTER(PreprocessConfig)]
+        L.ohw_default_preprocess_config.restype = None
+        L.ohw_preprocess_audio.argtypes = [fp, C.c_int64, C.c_uint32, C.POINTER(PreprocessConfig)]
+        L.ohw_dsp_rms_db.argtypes = [fp, C.c_int64]
+        L.ohw_dsp_rms_db.restype = C.c_float
+        L.ohw_dsp_apply_gain.argtypes = [fp, C.c_int64, C.c_float]
+        L.ohw_dsp_apply_gain.restype = None
+        L.ohw_dsp_normalize_rms.argtypes = [fp, C.c_int64, C.c_float]
+        L.ohw_dsp_normalize_rms.restype = None
+        L.ohw_dsp_compress.argtypes = [fp, C.c_int64, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.ohw_dsp_compress.restype = None
+        L.ohw_dsp_limit.argtypes = [fp, C.c_int64, C.c_uint32, C.c_float, C.c_float]
+        L.ohw_dsp_limit.restype = C.c_int64
+        L.ohw_dsp_resample_linear.argtypes = [fp, C.c_int64, C.c_uint32, C.c_uint32, fp, C.c_int64]
+        L.ohw_dsp_resample_linear.restype = C.c_int64
         L.ohw_stream_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.ohw_stream_destroy.argtypes = [vp]
         L.ohw_stream_wait.argtypes = [vp, vp]
@@ -463,6 +488,61 @@ class AudioBuffer:
 
     def duration_secs(self) -> float:
         return len(self.samples) / float(self.sample_rate)
+
+    # ---- the reference's AudioBuffer DSP (src/input/audio.rs:86-239), in place, through libohw (host code) ----
+    def _buf(self) -> np.ndarray:
+        if not (isinstance(self.samples, np.ndarray) and self.samples.dtype == np.float32 and self.samples.flags.c_contiguous
+                and self.samples.flags.writeable):
+            self.samples = np.array(self.samples, dtype=np.float32, order="C")
+        return self.samples
+
+    def rms_db(self) -> float:
+        b = self._buf()
+        return float(lib().ohw_dsp_rms_db(_fp(b) if b.size else C.cast(None, C.POINTER(C.c_float)), b.size))
+
+    def apply_gain(self, gain_db: float):
+        b = self._buf()
+        if b.size:
+            lib().ohw_dsp_apply_gain(_fp(b), b.size, gain_db)
+
+    def normalize_rms(self, target_db: float):
+        b = self._buf()
+        if b.size:
+            lib().ohw_dsp_normalize_rms(_fp(b), b.size, target_db)
+
+    def compress(self, threshold_db: float, ratio: float, attack_ms: float, release_ms: float, makeup_gain_db: float):
+        b = self._buf()
+        if b.size:
+            lib().ohw_dsp_compress(_fp(b), b.size, self.sample_rate, threshold_db, ratio, attack_ms, release_ms, makeup_gain_db)
+
+    def limit(self, ceiling_db: float, release_ms: float) -> int:
+        b = self._buf()
+        return int(lib().ohw_dsp_limit(_fp(b), b.size, self.sample_rate, ceiling_db, release_ms)) if b.size else 0
+
+    def preprocess(self, config: Optional["PreprocessConfig"] = None):
+        """TranscriptionWorker::preprocess_audio (reference src/queue/worker.rs:196-240) without RNNoise"""
+        b = self._buf()
+        cfg = config or default_preprocess_config()
+        if b.size:
+            _check(lib().ohw_preprocess_audio(_fp(b), b.size, self.sample_rate, C.byref(cfg)))
+
+
+def default_preprocess_config() -> PreprocessConfig:
+    c = PreprocessConfig()
+    lib().ohw_default_preprocess_config(C.byref(c))
+    return c
+
+
+def resample_linear(samples: np.ndarray, from_rate: int, to_rate: int) -> np.ndarray:
+    """resample(.., ResamplingQuality::Low) of the reference (src/input/audio.rs:960-990)"""
+    x = np.ascontiguousarray(samples, dtype=np.float32)
+    if x.size == 0:
+        return x.copy()
+    n = int(lib().ohw_dsp_resample_linear(_fp(x), x.size, from_rate, to_rate, C.cast(None, C.POINTER(C.c_float)), 0))
+    out = np.empty(n, np.float32)
+    if n:
+        lib().ohw_dsp_resample_linear(_fp(x), x.size, from_rate, to_rate, _fp(out), n)
+    return out
 
 
 @dataclasses.dataclass
