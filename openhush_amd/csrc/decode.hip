@@ -640,6 +640,103 @@ __global__ __launch_bounds__(XA_THREADS) void cross_attn_kernel(const T* __restr
   if (tid < 64) out[act_tiled_offset(m, h * 64 + tid, d)] = (T)(o / l);
   TRACE(3, 3);
 }
+// The prompt pass feeds n_new = 2..4 tokens per window at once: their query rows read the SAME 7.7 MB of cross K/V per
+// layer, so one workgroup takes all NQ rows of a (window, head) and streams K/V once (row by row it was read NQ times:
+// 3 x 246 MB per layer at 32 windows).  Per row the arithmetic and its order are those of cross_attn_kernel (bit-identical).
+template <typename T, int NQ>
+__global__ __launch_bounds__(XA_THREADS) void cross_attn_rows_kernel(const T* __restrict__ q, const T* __restrict__ xk, const T* __restrict__ xv,
+                                                                     T* __restrict__ out, int n_head, int t_len,
+                                                                     const int32_t* __restrict__ done) {
+  __shared__ float red_m[NQ][4], red_l[NQ][4];
+  __shared__ float red_o[NQ][4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, b = blockIdx.y;
+  if (done && done[b]) return;
+  const int d = n_head * 64;
+  const int part = lane & 7, slot = lane >> 3;
+  const float sc = 0.125f * 1.44269504088896340736f;
+  float qv[NQ][8], mrun[NQ], lrun[NQ], acc[NQ][8];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const vec8_t<T> qq = *(const vec8_t<T>*)(q + (int64_t)(b * NQ + i) * d + h * 64 + part * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { qv[i][e] = (float)qq[e] * sc; acc[i][e] = 0.f; }
+    mrun[i] = -INFINITY; lrun[i] = 0.f;
+  }
+  const T* kb = xk + (((int64_t)b * n_head + h) * t_len << 6) + part * 8;
+  const T* vb = xv + (((int64_t)b * n_head + h) * t_len << 6) + part * 8;
+  const int n_groups = (t_len + 7) / 8;
+  for (int g0 = wave; g0 < n_groups; g0 += 4 * XA_UNROLL) {
+    vec8_t<T> kf[XA_UNROLL], vf[XA_UNROLL];
+    int keys[XA_UNROLL];
+#pragma unroll
+    for (int u = 0; u < XA_UNROLL; ++u) {
+      const int g = g0 + 4 * u;
+      int key = g * 8 + slot;
+      keys[u] = (g < n_groups && key < t_len) ? key : -1;
+      if (key > t_len - 1) key = t_len - 1;
+      kf[u] = __builtin_nontemporal_load((const vec8_t<T>*)(kb + ((int64_t)key << 6)));
+      vf[u] = __builtin_nontemporal_load((const vec8_t<T>*)(vb + ((int64_t)key << 6)));
+    }
+#pragma unroll
+    for (int u = 0; u < XA_UNROLL; ++u) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += qv[i][e] * (float)kf[u][e];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (keys[u] < 0) s = -INFINITY;
+        const float mn = fmaxf(mrun[i], s);
+        const float alpha = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(mrun[i] - mn);
+        const float pe = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(s - mn);
+        mrun[i] = mn;
+        lrun[i] = lrun[i] * alpha + pe;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[i][e] = acc[i][e] * alpha + pe * (float)vf[u][e];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+#pragma unroll
+    for (int o = 8; o <= 32; o <<= 1) {
+      const float m2 = __shfl_xor(mrun[i], o, 64), l2 = __shfl_xor(lrun[i], o, 64);
+      const float mn = fmaxf(mrun[i], m2);
+      const float a1 = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(mrun[i] - mn);
+      const float a2 = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m2 - mn);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float o2 = __shfl_xor(acc[i][e], o, 64);
+        acc[i][e] = acc[i][e] * a1 + o2 * a2;
+      }
+      lrun[i] = lrun[i] * a1 + l2 * a2;
+      mrun[i] = mn;
+    }
+    if (slot == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red_o[i][wave][part * 8 + e] = acc[i][e];
+      if (part == 0) { red_m[i][wave] = mrun[i]; red_l[i][wave] = lrun[i]; }
+    }
+  }
+  __syncthreads();
+  // wave i finishes row i (NQ <= 4 waves)
+  if (wave < NQ) {
+    const int i = wave;
+    const float mn = fmaxf(fmaxf(red_m[i][0], red_m[i][1]), fmaxf(red_m[i][2], red_m[i][3]));
+    float l = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float a = red_m[i][w] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(red_m[i][w] - mn);
+      l += red_l[i][w] * a;
+      o += red_o[i][w][lane] * a;
+    }
+    out[act_tiled_offset(b * NQ + i, h * 64 + lane, d)] = (T)(o / l);
+  }
+}
+
 template <typename T>
 void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out, int M, int n_new, int n_head, int t_len, float* partials,
                        unsigned* tickets, int max_split_rows, const int32_t* done, hipStream_t s) {
@@ -647,6 +744,15 @@ void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out,
   int ks = 1;
   if (partials && tickets && M <= max_split_rows) {
     while (ks < XA_MAX_SPLIT && (int64_t)M * n_head * ks < 512 && t_len / (ks * 2) >= 64) ks *= 2;
+  }
+  // several new tokens per window and enough windows to fill the chip: one workgroup per (window, head) streams K/V once
+  if (n_new >= 2 && n_new <= 4 && M % n_new == 0 && (int64_t)(M / n_new) * n_head >= 256) {
+    const dim3 grid(n_head, M / n_new);
+    if (n_new == 2) hipLaunchKernelGGL((cross_attn_rows_kernel<T, 2>), grid, dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_head, t_len, done);
+    else if (n_new == 3) hipLaunchKernelGGL((cross_attn_rows_kernel<T, 3>), grid, dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_head, t_len, done);
+    else hipLaunchKernelGGL((cross_attn_rows_kernel<T, 4>), grid, dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_head, t_len, done);
+    HIP_CHECK(hipGetLastError());
+    return;
   }
   hipLaunchKernelGGL((cross_attn_kernel<T>), dim3(n_head, M, ks), dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_new,
                      n_head, t_len, partials, tickets, done);
