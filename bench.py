@@ -215,7 +215,7 @@ def main():
     # launch of one kernel class.  Events cannot be recorded inside a replayed graph, so these passes
     # launch the same kernels eagerly; only per-kernel durations are taken from them, never `value`.
     prof_class = args.profile_class
-    class_totals = {}
+    class_totals, class_work = {}, {}
     S_saved, S = S, 1          # the roofline leg runs sub-batch 0 alone, eagerly, on its own stream
     def step():                # noqa: F811
         out = [None]
@@ -227,6 +227,7 @@ def main():
             step()
             n, ms, w = st.profile_end()
             class_totals[cls] = ms
+            class_work[cls] = w
         prof_class = max(class_totals, key=class_totals.get)
     st.profile_begin(prof_class)
     for _ in range(args.steps):
@@ -252,6 +253,12 @@ def main():
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
         roof["traffic"] = pmc_traffic(prof_class, B)
+        # the path's MFMA-bound class beside the dominant (HBM-bound) kernel: BASELINE.json's north_star asks for both
+        mfma = None
+        if class_totals.get(1, 0) > 0 and class_work.get(1, 0) > 0:
+            tf = class_work[1] / (class_totals[1] * 1e-3) / 1e12
+            mfma = {"kernel": PROF_NAMES[1], "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / PEAK_MFMA_TFLOPS, 4), "ms_per_step": round(class_totals[1], 3)}
         roof.update({"kernel": PROF_NAMES[prof_class], "launches": launches, "avg_launch_us": round(1e3 * k_ms / max(1, launches), 2),
                      "kernel_ms_per_step": round(k_ms / args.steps, 3),
                      "class_ms_per_step": {PROF_NAMES[k]: round(v, 3) for k, v in class_totals.items()}})
@@ -267,7 +274,7 @@ def main():
                        "concurrent_sub_batches": S_saved, "pipeline": pipe,
                        "stage_ms_last_step": {"mel": round(tm.mel_ms, 2), "encode": round(tm.encode_ms, 2), "decode": round(tm.decode_ms, 2)},
                        "decode_steps": tm.decode_steps},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_mfma": mfma, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
