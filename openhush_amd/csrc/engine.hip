@@ -257,9 +257,9 @@ void run_encode(ohw_state* st, int B) {
   { ProfScope ps(st, OHW_PROF_ENC_GEMM, 2.0 * g.M * g.N * g.K); launch_gemm<T>(g, EPI_CROSSKV_T, s); }
 }
 
-// one decoder pass over M = B * n_new rows; tokens in st->step_tok, positions from st->n_past
+// one decoder pass over M = B * n_new rows; tokens in tok_src (default st->step_tok), positions from st->n_past
 template <typename T>
-void run_decoder_step(ohw_state* st, int B, int n_new) {
+void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = nullptr) {
   const ohw_ctx* c = st->ctx;
   const ohw_hparams& hp = c->hp;
   hipStream_t s = st->stream;
@@ -267,7 +267,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new) {
   const int M = B * n_new;
   if (M > st->m_max) throw Error(OHW_E_INVALID_ARG, "decode: batch * n_new exceeds the state's capacity (8 tokens per window per call)");
   const int32_t* n_past = st->n_past.as<int32_t>();
-  launch_embed<T>(c->emb.p, c->dec_pos.as<float>(), st->step_tok.as<int32_t>(), n_past, st->dx.as<float>(), M, n_new, d, s);
+  launch_embed<T>(c->emb.p, c->dec_pos.as<float>(), tok_src ? tok_src : st->step_tok.as<int32_t>(), n_past, st->dx.as<float>(), M, n_new, d, s);
   const int64_t kv_layer = (int64_t)st->max_batch * H * C * 64;      // elements per K (or V) cache of one layer
   const int64_t xkv_slab = (int64_t)B * H * Tn * 64;                 // cross K/V slab (batch of the last encode)
   auto gemm = [&](const void* x, const LayerNormW* ln, const DevBuf& w, const DevBuf& bias, void* out, int N, int K, int epi, int64_t ld) {
@@ -633,8 +633,7 @@ int ohw_greedy(ohw_state* st, const ohw_sample_params* sp, int batch, int32_t* t
         ohw_state::StepGraph ng;
         HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         try {
-          HIP_CHECK(hipMemcpyAsync(st->step_tok.p, st->next_tok.p, (size_t)batch * 4, hipMemcpyDeviceToDevice, s));
-          run_decoder_step<T>(st, batch, 1);
+          run_decoder_step<T>(st, batch, 1, st->next_tok.as<int32_t>());   // the token the sampler just wrote
           launch_sampler(spar, s);
         } catch (...) {
           hipGraph_t g = nullptr;
@@ -654,8 +653,7 @@ int ohw_greedy(ohw_state* st, const ohw_sample_params* sp, int batch, int32_t* t
         if (use_graph) {
           HIP_CHECK(hipGraphLaunch(step_exec, s));
         } else {
-          HIP_CHECK(hipMemcpyAsync(st->step_tok.p, st->next_tok.p, (size_t)batch * 4, hipMemcpyDeviceToDevice, s));
-          run_decoder_step<T>(st, batch, 1);
+          run_decoder_step<T>(st, batch, 1, st->next_tok.as<int32_t>());
           launch_sampler(spar, s);
         }
         ++steps;
