@@ -38,7 +38,7 @@ PROF_NAMES = {1: "gemm256_kernel (encoder / cross-KV MFMA GEMM)", 2: "encoder_at
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=32)

@@ -8,8 +8,8 @@ cd "${GRAFT_REPO_ROOT:-$PWD}"
 export TMPDIR=/tmp
 O=gpurun_out
 rm -rf $O/prof_final $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_GRBM_GUI_ACTIVE $O/pmc_sq
-echo "[profiles] bench bf16"; python3 bench.py --steps 3 --warmup 1 > $O/bench_final.json 2> $O/bench_final.err
-echo "[profiles] bench f16";  python3 bench.py --steps 3 --warmup 1 --dtype f16 --no-cpu-baseline > $O/bench_f16.json 2> $O/bench_f16.err
+echo "[profiles] bench bf16"; python3 bench.py > $O/bench_final.json 2> $O/bench_final.err
+echo "[profiles] bench f16";  python3 bench.py --dtype f16 --no-cpu-baseline > $O/bench_f16.json 2> $O/bench_f16.err
 echo "[profiles] kernel trace"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_final -- python3 bench.py --steps 3 --warmup 0 --no-cpu-baseline > $O/prof_final.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
