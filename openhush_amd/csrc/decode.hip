@@ -182,6 +182,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   // activation tiles: k-block kk of the 16-row tile mt is the 1 KiB at ((mt * kblocks + kk) * 64 + lane) * 8 elements
   const T* x0 = LN ? nullptr : x + ((int64_t)(m0 >> 4) * kblocks * 64 + lane) * 8;
   const T* x1 = LN ? nullptr : x0 + (int64_t)kblocks * 512;
+  const bool ok0 = m0 + (lane & 15) < p.M, ok1 = m0 + 16 + (lane & 15) < p.M;
   const unsigned char* y0 = ylds + (lane & 15) * ystride + (lane >> 4) * 16;
   const unsigned char* y1 = y0 + 16 * ystride;
   f32x4 acc[NT][2];
@@ -201,9 +202,30 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
       if constexpr (LN) {
         a[u] = *(const vec8*)(y0 + kk * 64);
         if constexpr (MT == 2) b[u] = *(const vec8*)(y1 + kk * 64);
+      }
+    }
+    if constexpr (!LN) {
+      // activation fragments: lanes whose row lies past M stay zero and load nothing (one exec-masked batch of loads,
+      // not a branch per load) - at batch 1 a 16-row tile holds one real row
+      if (ok0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = *(const vec8*)(x0 + (int64_t)(kb + DG_WAVES * u) * 512);
       } else {
-        a[u] = *(const vec8*)(x0 + (int64_t)kk * 512);
-        if constexpr (MT == 2) b[u] = *(const vec8*)(x1 + (int64_t)kk * 512);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[u][e] = 0;
+      }
+      if constexpr (MT == 2) {
+        if (ok1) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) b[u] = *(const vec8*)(x1 + (int64_t)(kb + DG_WAVES * u) * 512);
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[u][e] = 0;
+        }
       }
     }
     // keep every load above issued before the first MFMA (the scheduler otherwise sinks loads next to
@@ -254,10 +276,18 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
       for (int g = 0; g < UW; g += 5) {
         vec8 a[5], b[5];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-          const int kk = kb + DG_WAVES * (g + u);
-          a[u] = *(const vec8*)(x0 + (int64_t)kk * 512);
-          if constexpr (MT == 2) b[u] = *(const vec8*)(x1 + (int64_t)kk * 512);
+        for (int u = 0; u < 5; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { a[u][e] = 0; if constexpr (MT == 2) b[u][e] = 0; }
+        if (ok0) {
+#pragma unroll
+          for (int u = 0; u < 5; ++u) a[u] = *(const vec8*)(x0 + (int64_t)(kb + DG_WAVES * (g + u)) * 512);
+        }
+        if constexpr (MT == 2) {
+          if (ok1) {
+#pragma unroll
+            for (int u = 0; u < 5; ++u) b[u] = *(const vec8*)(x1 + (int64_t)(kb + DG_WAVES * (g + u)) * 512);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
