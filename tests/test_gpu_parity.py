@@ -298,6 +298,36 @@ def test_long_audio_two_batches_in_flight_equals_sequential(E, models, monkeypat
     assert len(out["0"][4]) == 4
 
 
+def test_cu_masked_streams_give_the_same_tokens(E, models):
+    """ohw_stream_create / _wait / _sync (include/ohw.h): the front end on a 96-CU stream, the decode on the other 160 CUs
+    (fewer CUs change which kernel variants run, never the result beyond fp32 re-association: same greedy tokens on this
+    model), and the error paths of the stream API."""
+    _, _, _, ctxs = models
+    ctx = ctxs[0]
+    pcm, ns = _pcm_batch()
+    p = ctx.default_params()
+    p.force_len = 16
+    st = E.State(ctx, 3)
+    st.mel(pcm, ns, E.OHW_MEL_ZERO_TAIL, want=False)
+    st.encode(3)
+    want, _ = st.greedy(3, p)
+    es, ds = E.Stream(0, 0, 96), E.Stream(0, 96, 160)
+    st2 = E.State(ctx, 3)
+    st2.set_stream(es.ptr)
+    st2.mel(pcm, ns, E.OHW_MEL_ZERO_TAIL, want=False)
+    st2.encode(3)
+    ds.wait(es)
+    st2.set_stream(ds.ptr)
+    got, _ = st2.greedy(3, p)
+    ds.sync()
+    assert got == want
+    st2.set_stream(None)
+    with pytest.raises(E.WhisperError):
+        E.Stream(0, 200, 100)            # past the device's 256 compute units
+    with pytest.raises(E.WhisperError):
+        E.Stream(99, 0, 0)
+
+
 def test_engine_error_paths(E, tmp_path):
     with pytest.raises(E.ModelNotFound) as ei:
         E.WhisperEngine.new(str(tmp_path / "ggml-small.bin"), "auto", False, True)
