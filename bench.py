@@ -266,7 +266,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(hp, pcm_host[:max(1, min(args.cpu_windows, B))], args.cpu_tokens or args.tokens)
         line = {
-            "metric": "audio-sec/sec (xRT) large-v3 greedy, 30s chunks", "value": round(value, 1), "unit": "audio-sec/sec",
+            "metric": baseline_metric(), "value": round(value, 1), "unit": "audio-sec/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.model} dims, batch={B} x 30 s windows per GPU, greedy, {args.tokens} tokens/window (EOT suppressed), "
@@ -280,6 +280,15 @@ def main():
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim (the file sits beside bench.py; the fallback is its text at round 1)"""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except (OSError, ValueError, KeyError):
+        return "audio-sec/sec (xRT) large-v3 greedy, 30s chunks, 1/2/4/8 MI355X"
 
 
 def pmc_traffic(prof_class, batch):
