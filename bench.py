@@ -59,6 +59,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 path on a ONE-GPU box: OHW_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo (RCCL needs
+    # one device per rank).  Never set by the driver; numbers from such a run mean nothing.
+    rehearse = os.environ.get("OHW_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -76,7 +81,10 @@ def main():
             os.environ["NCCL_DEBUG"] = os.environ["OHW_NCCL_DEBUG"]
         else:
             os.environ.pop("NCCL_DEBUG", None)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     hp = synth.PRESETS[args.model]
     dtype = E.OHW_DTYPE_BF16 if args.dtype == "bf16" else E.OHW_DTYPE_F16
