@@ -51,7 +51,7 @@ def main():
                          "decoder of batch i on the rest; 0: one batch after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=0, help="decode tokens in the CPU sample (0 = same as --tokens)")
-    ap.add_argument("--cpu-windows", type=int, default=3, help="30 s windows in the CPU sample")
+    ap.add_argument("--cpu-windows", type=int, default=2, help="30 s windows in the CPU sample")
     args = ap.parse_args()
 
     import torch
@@ -260,7 +260,15 @@ def main():
             achieved = work / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
-        roof["traffic"] = pmc_traffic(prof_class, B)
+        roof["traffic"], roof["traffic_source"] = pmc_traffic(prof_class, B)
+        # whole path against its own bounds ("whole-path roofline = sum of stage times at their own bound"):
+        # MFMA classes at the dense 16-bit peak, HBM classes (algorithmic bytes) and the mel's 3.46 MB per window at 8 TB/s
+        if class_work:
+            mfma_ms = 1e3 * (class_work.get(1, 0.0) + class_work.get(2, 0.0)) / (PEAK_MFMA_TFLOPS * 1e12)
+            hbm_ms = 1e3 * (sum(class_work.get(c, 0.0) for c in range(3, 9)) + B * (480000 * 4 + hp.n_mels * 3000 * 4)) / (PEAK_HBM_GBS * 1e9)
+            ms_step = 1e3 * dt_max / args.steps
+            roof["whole_path"] = {"bound_ms_per_step": round(mfma_ms + hbm_ms, 2), "mfma_bound_ms": round(mfma_ms, 2), "hbm_bound_ms": round(hbm_ms, 2),
+                                  "measured_ms_per_step": round(ms_step, 2), "frac": round((mfma_ms + hbm_ms) / ms_step, 4)}
         # the path's MFMA-bound class beside the dominant (HBM-bound) kernel: BASELINE.json's north_star asks for both
         mfma = None
         if class_totals.get(1, 0) > 0 and class_work.get(1, 0) > 0:
@@ -273,6 +281,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(hp, pcm_host[:max(1, min(args.cpu_windows, B))], args.cpu_tokens or args.tokens)
+        print(f"[bench] rank 0 ok: {value:.1f} audio-s/s over {world} rank(s)", file=sys.stderr, flush=True)
         line = {
             "metric": baseline_metric(), "value": round(value, 1), "unit": "audio-sec/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 2),
@@ -287,7 +296,19 @@ def main():
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
     if use_dist:
+        # every rank's exit is visible: a rank reports, all ranks meet once more, then tear down (a rank that dies before
+        # this line leaves the others' barrier to fail loudly instead of a silent non-zero exit at interpreter shutdown)
+        if rank != 0:
+            print(f"[bench] rank {rank} ok", file=sys.stderr, flush=True)
+        dist.barrier()
         dist.destroy_process_group()
+    # release the device objects in a defined order (states and streams before their context) rather than at interpreter exit
+    for s_ in states + (pipe and pst[1:] or []):
+        s_.close()
+    if pipe:
+        for x in (es, ds, full):
+            x.close()
+    ctx.close()
 
 
 def baseline_metric():
@@ -300,18 +321,22 @@ def baseline_metric():
 
 
 def pmc_traffic(prof_class, batch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_summary.json: FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE, separate passes).
-    bench.py cannot run the profiler around itself; null when no committed figure matches this workload."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-            pm = json.load(f)
-        ent = pm.get(str(prof_class))
-        if ent and ent.get("batch") == batch:
-            return ent["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    """(HBM bytes per launch of the dominant kernel, where the figure comes from).  bench.py cannot run the profiler
+    around itself: the figure is read from the newest committed rocprofv3 PMC summary (profiles/rNN_pmc_summary.json:
+    FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE, separate --pmc passes of this command at a reduced token
+    count, tools/run_profiles.sh) and labelled as such; (None, reason) when no committed figure matches this workload."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+        try:
+            with open(path) as f:
+                pm = json.load(f)
+            ent = pm.get(str(prof_class))
+            if ent and ent.get("batch") == batch:
+                return ent["hbm_bytes_per_launch"], (f"committed PMC pass profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                                     "separate runs of this command at --tokens 6), not measured in this run")
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, "no committed PMC pass matches this kernel class and batch"
 
 
 def usable_cores() -> int:
@@ -335,29 +360,49 @@ def usable_cores() -> int:
     return max(1, min(n, int(os.environ.get("OHW_CPU_BASELINE_THREADS", "16"))))
 
 
+def cpu_model_name() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(hp, pcm, n_tokens):
-    """The oracle (kind "port") on this host's cores: ONE 30 s window of the same workload."""
+    """The oracle (kind "port") on this host's cores, a bounded sample of the same workload, at the two thread counts
+    SURVEY.md 8d names: 4 (the reference engine's effective default: whisper.cpp n_threads = min(4, cores)) and every
+    usable core.  `value` / `cores` are the all-cores leg; `runs` holds both."""
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # before libgomp loads: no spinning if oversubscribed
     from oracle import oracle
     cores = usable_cores()
     oracle.set_num_threads(cores)
     print(f"[bench] cpu_baseline: generating the model on the host ({cores} threads) ...", file=sys.stderr, flush=True)
     m = oracle.Model.synth(hp.as_list(), 1234)
-    print("[bench] cpu_baseline: transcribing one 30 s window with the oracle ...", file=sys.stderr, flush=True)
     p = m.default_params()
     p.force_len = n_tokens
-    t0 = time.perf_counter()
-    t_mel = t_enc = t_dec = 0.0
-    for w in range(len(pcm)):
-        toks, (a, b, c) = m.transcribe_chunk(pcm[w], p, 1)
-        assert len(toks) == n_tokens
-        t_mel += a; t_enc += b; t_dec += c
-        print(f"[bench] cpu_baseline: window {w + 1}/{len(pcm)} done", file=sys.stderr, flush=True)
-    dt = time.perf_counter() - t0
+    runs = []
+    legs = [(cores, len(pcm))] + ([(4, 1)] if cores > 4 else [])       # the 4-thread leg: one window (about 30 s of CPU work)
+    for threads, n_win in legs:
+        oracle.set_num_threads(threads)
+        t0 = time.perf_counter()
+        t_mel = t_enc = t_dec = 0.0
+        for w in range(n_win):
+            toks, (a, b, c) = m.transcribe_chunk(pcm[w], p, 1)
+            assert len(toks) == n_tokens
+            t_mel += a; t_enc += b; t_dec += c
+            print(f"[bench] cpu_baseline: {threads} threads, window {w + 1}/{n_win} done", file=sys.stderr, flush=True)
+        dt = time.perf_counter() - t0
+        runs.append({"cores": threads, "value": round(30.0 * n_win / dt, 3), "windows": n_win,
+                     "stage_s": {"mel": round(t_mel, 2), "encoder+crossKV": round(t_enc, 2), "decode": round(t_dec, 2)}})
     m.close()
-    return {"value": round(30.0 * len(pcm) / dt, 3), "unit": "audio-sec/sec", "cores": cores, "kind": "port",
-            "sample": f"{len(pcm)} windows (30 s each) of the same workload, {n_tokens} decode tokens per window, fp32 C/OpenMP oracle "
-                      f"(x86-64-v3): mel {t_mel:.2f} s, encoder+crossKV {t_enc:.2f} s, decode {t_dec:.2f} s"}
+    top = runs[0]
+    return {"value": top["value"], "unit": "audio-sec/sec", "cores": top["cores"], "kind": "port", "cpu_model": cpu_model_name(),
+            "sample": f"{top['windows']} windows (30 s each) of the same workload, {n_tokens} decode tokens per window, fp32 C/OpenMP oracle "
+                      f"(x86-64-v3): mel {top['stage_s']['mel']:.2f} s, encoder+crossKV {top['stage_s']['encoder+crossKV']:.2f} s, "
+                      f"decode {top['stage_s']['decode']:.2f} s; second leg at 4 threads (the reference engine's default) on 1 window",
+            "runs": runs}
 
 
 if __name__ == "__main__":

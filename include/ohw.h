@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OHW_ABI_VERSION 1
+#define OHW_ABI_VERSION 2
 
 /* error codes: the negated OH-30xx taxonomy the reference documents
  * (reference .claude/knowledge/error-codes.md:79-104; WhisperError variants src/engine/whisper.rs:14-27) */
@@ -181,6 +181,25 @@ int32_t ohw_sample_greedy_host(const ohw_ctx* ctx, const ohw_sample_params* p, f
 int ohw_greedy(ohw_state* st, const ohw_sample_params* p, int batch, int32_t* tokens_out, int32_t* n_tokens_out,
                int max_tokens, float* sum_logprob_out /* [batch] or NULL */);
 
+/* the same loop, with everything whisper.cpp's per-window bookkeeping needs: the log-probability of
+ * every sampled token - whisper.cpp's avg_logprobs sums the end-of-text token's too: it is slot n_tokens[b] when
+ * ended_by_eot[b] - and the no-speech probability of the window (soft-max of the first, unfiltered logits row at the
+ * no-speech token).  Every pointer except tokens / n_tokens may be NULL. */
+typedef struct {
+  int32_t* tokens;        /* [batch][max_tokens] */
+  int32_t* n_tokens;      /* [batch] */
+  float* sum_logprob;     /* [batch]: sum over the stored tokens (end-of-text excluded) */
+  float* token_logprobs;  /* [batch][max_tokens + 1] */
+  int32_t* ended_by_eot;  /* [batch]: 1 = end-of-text was sampled, 0 = a length limit stopped the window */
+  float* no_speech_prob;  /* [batch] */
+} ohw_greedy_result;
+int ohw_greedy_ex(ohw_state* st, const ohw_sample_params* p, int batch, int max_tokens, const ohw_greedy_result* out);
+
+/* additive bias on every logits row before the filter, bias[n_vocab] (host; copied), NULL clears it.  This is the
+ * engine's form of whisper.cpp's logits_filter_callback (whisper_full_params; the reference sets none,
+ * src/engine/whisper.rs:243-263, so the default is no bias); tests use it to make end-of-text and timestamps win. */
+int ohw_state_set_logit_bias(ohw_state* st, const float* bias, int n);
+
 /* per-stage device time of the last calls on this state, in milliseconds (reference logs the     */
 /* same split per job: src/queue/worker.rs:170-180)                                               */
 typedef struct { float mel_ms, encode_ms, decode_ms, total_ms; int32_t decode_steps; } ohw_timings;
@@ -249,6 +268,11 @@ int ohw_ctx_weight_digest(const ohw_ctx* ctx, int index, char* name_out /* >= 64
 int ohw_dbg_gemm(int dtype, const void* A, const void* W, const float* bias, void* out, int64_t M, int64_t N,
                  int64_t K, int epilogue, void* stream);
 int ohw_dbg_attention(int dtype, const void* qkv, void* out, int batch, int T, int n_head, void* stream);
+/* the DEVICE sampler on caller-supplied rows: logits [batch][n_vocab] (host), history [batch][hist_stride] with
+ * n_hist[b] tokens sampled so far in the window.  tokens_out [batch]: the pick (end-of-text included);
+ * logprobs_out [batch] / no_speech_out [batch] may be NULL (no-speech is defined for rows with n_hist == 0). */
+int ohw_dbg_sample(ohw_state* st, const ohw_sample_params* p, const float* logits, const int32_t* history, int hist_stride,
+                   const int32_t* n_hist, int batch, int32_t* tokens_out, float* logprobs_out, float* no_speech_out);
 
 #ifdef __cplusplus
 }

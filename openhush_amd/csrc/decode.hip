@@ -818,6 +818,7 @@ struct SampAcc {
   float m, s_all, s_ts;     // online log-sum-exp state: sums are relative to m
   float tv; int ti;         // best text token  (value, index)
   float zv; int zi;         // best timestamp token
+  float rm, rs;             // first step only: log-sum-exp state of the UNFILTERED row (no-speech probability)
 };
 
 __device__ __forceinline__ void samp_merge(SampAcc& a, const SampAcc& b) {
@@ -829,6 +830,11 @@ __device__ __forceinline__ void samp_merge(SampAcc& a, const SampAcc& b) {
   a.m = mn;
   if (b.tv > a.tv || (b.tv == a.tv && b.ti < a.ti)) { a.tv = b.tv; a.ti = b.ti; }
   if (b.zv > a.zv || (b.zv == a.zv && b.zi < a.zi)) { a.zv = b.zv; a.zi = b.zi; }
+  const float rn = fmaxf(a.rm, b.rm);
+  const float ra = a.rm == -INFINITY ? 0.f : expf(a.rm - rn);
+  const float rb = b.rm == -INFINITY ? 0.f : expf(b.rm - rn);
+  a.rs = a.rs * ra + b.rs * rb;
+  a.rm = rn;
 }
 
 // ONE pass over the logits row: masked online log-sum-exp (all / timestamps) and the best text and
@@ -853,8 +859,10 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_kernel(SamplerParams p) {
   st.suppress_eot = p.force_len > 0 && n_cur < p.force_len;
   const int per = (p.n_vocab + SAMPLER_SPLIT - 1) / SAMPLER_SPLIT;
   const int lo = part * per, V = lo + per < p.n_vocab ? lo + per : p.n_vocab;
+  const bool want_raw = st.is_initial && p.nosp_prob != nullptr;
   SampAcc a;
   a.m = -INFINITY; a.s_all = 0.f; a.s_ts = 0.f; a.tv = -INFINITY; a.ti = 0x7fffffff; a.zv = -INFINITY; a.zi = 0x7fffffff;
+  a.rm = -INFINITY; a.rs = 0.f;
   // batches of SP_BATCH loads per thread, all in flight before the first is used
   constexpr int SP_BATCH = 13;
   TRACE(4, 0);
@@ -864,6 +872,26 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_kernel(SamplerParams p) {
     for (int u = 0; u < SP_BATCH; ++u) {
       const int i = i0 + u * SP_THREADS;
       vv[u] = lg[i < V ? i : V - 1];           // unconditional load (clamped address); masked below
+    }
+    if (p.bias) {
+      float bb[SP_BATCH];
+#pragma unroll
+      for (int u = 0; u < SP_BATCH; ++u) {
+        const int i = i0 + u * SP_THREADS;
+        bb[u] = p.bias[i < V ? i : V - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < SP_BATCH; ++u) vv[u] += bb[u];
+    }
+    if (want_raw) {
+#pragma unroll
+      for (int u = 0; u < SP_BATCH; ++u) {
+        const int i = i0 + u * SP_THREADS;
+        const float v = vv[u];
+        if (i >= V) continue;
+        if (v > a.rm) { a.rs *= a.rm == -INFINITY ? 0.f : expf(a.rm - v); a.rm = v; }
+        a.rs += expf(v - a.rm);
+      }
     }
 #pragma unroll
     for (int u = 0; u < SP_BATCH; ++u) {
@@ -886,6 +914,7 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_kernel(SamplerParams p) {
     SampAcc bb;
     bb.m = __shfl_xor(a.m, o, 64); bb.s_all = __shfl_xor(a.s_all, o, 64); bb.s_ts = __shfl_xor(a.s_ts, o, 64);
     bb.tv = __shfl_xor(a.tv, o, 64); bb.ti = __shfl_xor(a.ti, o, 64); bb.zv = __shfl_xor(a.zv, o, 64); bb.zi = __shfl_xor(a.zi, o, 64);
+    bb.rm = __shfl_xor(a.rm, o, 64); bb.rs = __shfl_xor(a.rs, o, 64);
     samp_merge(a, bb);
   }
   if ((tid & 63) == 0) sh[tid >> 6] = a;
@@ -893,27 +922,33 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_kernel(SamplerParams p) {
   if (tid == 0) {
     for (int w = 1; w < SP_THREADS / 64; ++w) samp_merge(a, sh[w]);
     // publish this slice, take a ticket; only the last arriver goes on (one thread does all of it, in program order)
-    unsigned* slot = (unsigned*)p.partials + ((int64_t)b * SAMPLER_SPLIT + part) * 8;
-    const unsigned words[7] = {__float_as_uint(a.m), __float_as_uint(a.s_all), __float_as_uint(a.s_ts), __float_as_uint(a.tv), (unsigned)a.ti,
-                               __float_as_uint(a.zv), (unsigned)a.zi};
+    constexpr int NW = 9;
+    unsigned* slot = (unsigned*)p.partials + ((int64_t)b * SAMPLER_SPLIT + part) * SAMPLER_PART_WORDS;
+    const unsigned words[NW] = {__float_as_uint(a.m), __float_as_uint(a.s_all), __float_as_uint(a.s_ts), __float_as_uint(a.tv), (unsigned)a.ti,
+                                __float_as_uint(a.zv), (unsigned)a.zi, __float_as_uint(a.rm), __float_as_uint(a.rs)};
 #pragma unroll
-    for (int k = 0; k < 7; ++k) __hip_atomic_store(slot + k, words[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < NW; ++k) __hip_atomic_store(slot + k, words[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned ticket = __hip_atomic_fetch_add(p.tickets + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ticket == SAMPLER_SPLIT - 1) {
       __hip_atomic_store(p.tickets + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned* all = (const unsigned*)p.partials + (int64_t)b * SAMPLER_SPLIT * 8;
-      unsigned w8[SAMPLER_SPLIT][7];
+      const unsigned* all = (const unsigned*)p.partials + (int64_t)b * SAMPLER_SPLIT * SAMPLER_PART_WORDS;
+      unsigned w8[SAMPLER_SPLIT][NW];
 #pragma unroll
       for (int q = 0; q < SAMPLER_SPLIT; ++q)
 #pragma unroll
-        for (int k = 0; k < 7; ++k) w8[q][k] = __hip_atomic_load(all + q * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < NW; ++k) w8[q][k] = __hip_atomic_load(all + q * SAMPLER_PART_WORDS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
       for (int q = 0; q < SAMPLER_SPLIT; ++q) {
         SampAcc c;
         c.m = __uint_as_float(w8[q][0]); c.s_all = __uint_as_float(w8[q][1]); c.s_ts = __uint_as_float(w8[q][2]);
         c.tv = __uint_as_float(w8[q][3]); c.ti = (int)w8[q][4]; c.zv = __uint_as_float(w8[q][5]); c.zi = (int)w8[q][6];
+        c.rm = __uint_as_float(w8[q][7]); c.rs = __uint_as_float(w8[q][8]);
         if (q == 0) a = c; else samp_merge(a, c);
+      }
+      if (want_raw) {
+        const float v = lg[p.nosp] + (p.bias ? p.bias[p.nosp] : 0.f);
+        p.nosp_prob[b] = expf(v - (a.rm + logf(a.rs)));
       }
       const float lse = a.m + logf(a.s_all);
       bool force_ts = false;
@@ -927,8 +962,10 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_kernel(SamplerParams p) {
       if (force_ts || a.zv > a.tv) { bv = a.zv; bi = a.zi; } else { bv = a.tv; bi = a.ti; }
       const int n_max = p.force_len > 0 ? p.force_len : p.n_max;
       bool finished = false;
+      if (p.tok_lp) p.tok_lp[(int64_t)b * (p.max_tokens + 1) + n_cur] = bv - lse;
       if (bi == p.eot) {
         finished = true;
+        p.next_tok[b] = bi;
       } else {
         toks[n_cur] = bi;
         p.n_cur[b] = n_cur + 1;

@@ -84,6 +84,9 @@ struct ohw_state {
   DevBuf xa_part, xa_ticket;       // cross-attention over key slices (small batches)
   int xa_rows = 0;
   DevBuf step_tok, n_past, tokens, n_cur, next_tok, done, n_done, sum_lp;
+  DevBuf tok_lp, nosp_prob;        // per-token log-probabilities [B][max_tokens + 1], no-speech probability [B]
+  DevBuf logit_bias;               // optional f32 [n_vocab] (ohw_state_set_logit_bias)
+  bool bias_on = false;
   int m_max = 0;
   int64_t logits_ld = 0;
   // per-kernel-class profiling (bench): event pairs around every launch of one class
@@ -168,7 +171,7 @@ void state_alloc(ohw_state* st) {
     const size_t tiles = (size_t)((dt + 15) / 16) * ((st->m_max + 31) / 32);
     st->ks_slab.alloc(tiles * DEC_KSPLIT_MAX * 2048);
     st->ks_ticket.alloc(tiles * 4, true);
-    st->samp_part.alloc((size_t)B * SAMPLER_SPLIT * 8 * 4, true);
+    st->samp_part.alloc((size_t)B * SAMPLER_SPLIT * SAMPLER_PART_WORDS * 4, true);
     st->samp_ticket.alloc((size_t)B * 4, true);
     st->xa_rows = std::min(st->m_max, 24);       // 24 rows x 20 heads is already two (row, head) pairs per CU
     st->xa_part.alloc((size_t)st->xa_rows * H * XA_MAX_SPLIT * 68 * 4, true);
@@ -187,6 +190,8 @@ void state_alloc(ohw_state* st) {
   st->done.alloc((size_t)B * 4, true);
   st->n_done.alloc(16, true);
   st->sum_lp.alloc((size_t)B * 4, true);
+  st->tok_lp.alloc((size_t)B * (st->max_tokens + 1) * 4, true);
+  st->nosp_prob.alloc((size_t)B * 4, true);
   for (auto& e : st->ev) HIP_CHECK(hipEventCreate(&e));
 }
 
@@ -285,7 +290,8 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
     p.d_model = d; p.n_head = H; p.n_ctx = C;
     const int cls = epi == DEPI_BIAS_T ? OHW_PROF_DEC_GEMM_XQ : epi == DEPI_BIAS_GELU_T ? OHW_PROF_DEC_GEMM_FC1
                   : epi == DEPI_LOGITS ? OHW_PROF_DEC_GEMM_LOGITS : OHW_PROF_DEC_GEMM;
-    ProfScope ps(st, cls, 2.0 * ((double)((N + 15) / 16 * 16) * K) * ((M + 31) / 32));
+    // algorithmic bytes: the weights once per launch (the m-blocks of a prompt pass share them through L2)
+    ProfScope ps(st, cls, 2.0 * (double)N * K);
     launch_dec_gemm<T>(p, epi, s);
   };
   for (int l = 0; l < L; ++l) {
@@ -298,14 +304,17 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
       p.w = w.wqkv.p; p.bias = w.bqkv.as<float>(); p.out = st->dq.p;
       p.M = M; p.N = 3 * d; p.K = d; p.n_new = n_new; p.ld_out = d;
       p.k_cache = kc; p.v_cache = vc; p.n_past = n_past; p.d_model = d; p.n_head = H; p.n_ctx = C;
-      ProfScope ps(st, OHW_PROF_DEC_GEMM_QKV, 2.0 * (3.0 * d * d) * ((M + 31) / 32));
+      ProfScope ps(st, OHW_PROF_DEC_GEMM_QKV, 2.0 * (3.0 * d * d));
       launch_dec_gemm<T>(p, DEPI_QKV, s);
     }
     launch_self_attn<T>(st->dq.p, kc, vc, n_past, st->da.p, M, n_new, H, C, s);
     gemm(st->da.p, nullptr, w.wo, w.bo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
     gemm(st->dx.p, &w.lnx, w.wxq, w.bxq, st->dq.p, d, d, DEPI_BIAS_T, d);
     {
-      ProfScope psx(st, OHW_PROF_DEC_XATTN, 2.0 * 2.0 * (double)M * H * Tn * 64.0);
+      // algorithmic bytes: K and V of every (query row, head); the prompt pass streams them once per (window, head)
+      // for all its rows (cross_attn_rows_kernel: same condition as launch_cross_attn)
+      const bool rows_path = n_new >= 2 && n_new <= 4 && (int64_t)B * H >= 256;
+      ProfScope psx(st, OHW_PROF_DEC_XATTN, 2.0 * 2.0 * (double)(rows_path ? B : M) * H * Tn * 64.0);
       launch_cross_attn<T>(st->dq.p, (const T*)st->xkv.p + (int64_t)(2 * l) * xkv_slab, (const T*)st->xkv.p + (int64_t)(2 * l + 1) * xkv_slab,
                            st->da.p, M, n_new, H, Tn, st->xa_part.as<float>(), st->xa_ticket.as<unsigned>(), st->xa_rows,
                            st->skip_done ? st->done.as<int32_t>() : nullptr, s);
@@ -327,6 +336,8 @@ void fill_sampler(const ohw_state* st, const ohw_sample_params* sp, int B, Sampl
   p->next_tok = st->next_tok.as<int32_t>(); p->done = st->done.as<int32_t>(); p->n_done = st->n_done.as<int32_t>();
   p->sum_logprob = st->sum_lp.as<float>();
   p->partials = st->samp_part.as<float>(); p->tickets = st->samp_ticket.as<unsigned>();
+  p->bias = st->bias_on ? st->logit_bias.as<float>() : nullptr;
+  p->tok_lp = st->tok_lp.as<float>(); p->nosp_prob = st->nosp_prob.as<float>();
   p->batch = B; p->max_tokens = st->max_tokens; p->n_vocab = c->hp.n_vocab;
   p->eot = c->tok.eot; p->sot = c->tok.sot; p->translate = c->tok.translate; p->transcribe = c->tok.transcribe;
   p->solm = c->tok.solm; p->prev = c->tok.prev; p->nosp = c->tok.nosp; p->no_ts = c->tok.no_timestamps;
@@ -574,10 +585,12 @@ void ohw_default_sample_params(const ohw_ctx* ctx, ohw_sample_params* p) {
   p->force_len = 0;
 }
 
-int ohw_greedy(ohw_state* st, const ohw_sample_params* sp, int batch, int32_t* tokens_out, int32_t* n_tokens_out, int max_tokens,
-               float* sum_logprob_out) {
+int ohw_greedy_ex(ohw_state* st, const ohw_sample_params* sp, int batch, int max_tokens, const ohw_greedy_result* res) {
   return guard([&] {
-    if (!st || !sp || !tokens_out || !n_tokens_out) throw Error(OHW_E_INVALID_ARG, "null argument");
+    if (!st || !sp || !res || !res->tokens || !res->n_tokens) throw Error(OHW_E_INVALID_ARG, "null argument");
+    int32_t* tokens_out = res->tokens;
+    int32_t* n_tokens_out = res->n_tokens;
+    float* sum_logprob_out = res->sum_logprob;
     if (batch < 1 || batch != st->enc_batch) throw Error(OHW_E_INVALID_ARG, "greedy: batch must equal the batch of the last ohw_encode");
     const ohw_ctx* c = st->ctx;
     if (sp->lang_id < 0 || sp->lang_id >= c->tok.n_langs) throw Error(OHW_E_INVALID_ARG, "greedy: lang_id out of range");
@@ -597,6 +610,8 @@ int ohw_greedy(ohw_state* st, const ohw_sample_params* sp, int batch, int32_t* t
     HIP_CHECK(hipMemsetAsync(st->done.p, 0, (size_t)batch * 4, s));
     HIP_CHECK(hipMemsetAsync(st->n_done.p, 0, 16, s));
     HIP_CHECK(hipMemsetAsync(st->sum_lp.p, 0, (size_t)batch * 4, s));
+    HIP_CHECK(hipMemsetAsync(st->next_tok.p, 0, (size_t)batch * 4, s));
+    HIP_CHECK(hipMemsetAsync(st->nosp_prob.p, 0, (size_t)batch * 4, s));
     SamplerParams spar;
     ohw_sample_params eff = *sp;
     eff.n_max = n_max;
@@ -669,13 +684,90 @@ int ohw_greedy(ohw_state* st, const ohw_sample_params* sp, int batch, int32_t* t
     HIP_CHECK(hipMemcpyAsync(toks.data(), st->tokens.p, toks.size() * 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(ncur.data(), st->n_cur.p, ncur.size() * 4, hipMemcpyDeviceToHost, s));
     if (sum_logprob_out) HIP_CHECK(hipMemcpyAsync(sum_logprob_out, st->sum_lp.p, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> last((size_t)batch);
+    std::vector<float> lps;
+    HIP_CHECK(hipMemcpyAsync(last.data(), st->next_tok.p, last.size() * 4, hipMemcpyDeviceToHost, s));
+    if (res->no_speech_prob) HIP_CHECK(hipMemcpyAsync(res->no_speech_prob, st->nosp_prob.p, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+    if (res->token_logprobs) {
+      lps.resize((size_t)batch * (st->max_tokens + 1));
+      HIP_CHECK(hipMemcpyAsync(lps.data(), st->tok_lp.p, lps.size() * 4, hipMemcpyDeviceToHost, s));
+    }
     HIP_CHECK(hipStreamSynchronize(s));
     for (int b = 0; b < batch; ++b) {
       const int n = std::min(ncur[(size_t)b], max_tokens);
       n_tokens_out[b] = n;
       std::memcpy(tokens_out + (size_t)b * max_tokens, &toks[(size_t)b * st->max_tokens], (size_t)n * 4);
+      const bool eot = last[(size_t)b] == c->tok.eot && ncur[(size_t)b] <= max_tokens;
+      if (res->ended_by_eot) res->ended_by_eot[b] = eot ? 1 : 0;
+      if (res->token_logprobs) {
+        float* dst = res->token_logprobs + (size_t)b * (max_tokens + 1);
+        const int m = std::min(n + (eot ? 1 : 0), max_tokens + 1);
+        std::memcpy(dst, &lps[(size_t)b * (st->max_tokens + 1)], (size_t)m * 4);
+      }
     }
     st->last.decode_steps = steps;
+  });
+}
+
+int ohw_greedy(ohw_state* st, const ohw_sample_params* sp, int batch, int32_t* tokens_out, int32_t* n_tokens_out, int max_tokens,
+               float* sum_logprob_out) {
+  ohw_greedy_result r{};
+  r.tokens = tokens_out; r.n_tokens = n_tokens_out; r.sum_logprob = sum_logprob_out;
+  return ohw_greedy_ex(st, sp, batch, max_tokens, &r);
+}
+
+int ohw_state_set_logit_bias(ohw_state* st, const float* bias, int n) {
+  return guard([&] {
+    if (!st) throw Error(OHW_E_INVALID_ARG, "state is null");
+    HIP_CHECK(hipSetDevice(st->ctx->device));
+    HIP_CHECK(hipStreamSynchronize(st->stream));
+    if (!bias) { st->bias_on = false; return; }
+    if (n != st->ctx->hp.n_vocab) throw Error(OHW_E_INVALID_ARG, "logit bias: n must equal n_vocab");
+    if (!st->logit_bias.p) st->logit_bias.alloc((size_t)n * 4);
+    HIP_CHECK(hipMemcpy(st->logit_bias.p, bias, (size_t)n * 4, hipMemcpyHostToDevice));
+    st->bias_on = true;
+  });
+}
+
+// test entry: the device sampler on caller-supplied rows.  logits [batch][n_vocab] (host), history [batch][hist_stride]
+// with n_hist[b] tokens sampled so far.  Returns the token the sampler picks per row (end-of-text included), its
+// log-probability, and the first-step no-speech probability (rows with n_hist == 0; 0 elsewhere).
+int ohw_dbg_sample(ohw_state* st, const ohw_sample_params* sp, const float* logits, const int32_t* history, int hist_stride,
+                   const int32_t* n_hist, int batch, int32_t* tokens_out, float* logprobs_out, float* no_speech_out) {
+  return guard([&] {
+    if (!st || !sp || !logits || !n_hist || !tokens_out) throw Error(OHW_E_INVALID_ARG, "null argument");
+    if (batch < 1 || batch > st->max_batch) throw Error(OHW_E_INVALID_ARG, "dbg_sample: batch exceeds the state's max_batch");
+    const ohw_ctx* c = st->ctx;
+    const int V = c->hp.n_vocab;
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = st->stream;
+    std::vector<int32_t> hist((size_t)batch * st->max_tokens, 0), ncur((size_t)batch);
+    for (int b = 0; b < batch; ++b) {
+      if (n_hist[b] < 0 || n_hist[b] >= st->max_tokens || n_hist[b] > hist_stride || (n_hist[b] > 0 && !history))
+        throw Error(OHW_E_INVALID_ARG, "dbg_sample: bad history length");
+      ncur[(size_t)b] = n_hist[b];
+      for (int i = 0; i < n_hist[b]; ++i) hist[(size_t)b * st->max_tokens + i] = history[(size_t)b * hist_stride + i];
+    }
+    HIP_CHECK(hipMemcpy2DAsync(st->logits.p, (size_t)st->logits_ld * 4, logits, (size_t)V * 4, (size_t)V * 4, (size_t)batch, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(st->tokens.p, hist.data(), hist.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(st->n_cur.p, ncur.data(), ncur.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemsetAsync(st->n_past.p, 0, (size_t)batch * 4, s));
+    HIP_CHECK(hipMemsetAsync(st->done.p, 0, (size_t)batch * 4, s));
+    HIP_CHECK(hipMemsetAsync(st->n_done.p, 0, 16, s));
+    HIP_CHECK(hipMemsetAsync(st->sum_lp.p, 0, (size_t)batch * 4, s));
+    HIP_CHECK(hipMemsetAsync(st->next_tok.p, 0, (size_t)batch * 4, s));
+    HIP_CHECK(hipMemsetAsync(st->nosp_prob.p, 0, (size_t)batch * 4, s));
+    SamplerParams spar;
+    fill_sampler(st, sp, batch, &spar);
+    spar.advance = 0;
+    launch_sampler(spar, s);
+    std::vector<float> lps((size_t)batch * (st->max_tokens + 1));
+    HIP_CHECK(hipMemcpyAsync(tokens_out, st->next_tok.p, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(lps.data(), st->tok_lp.p, lps.size() * 4, hipMemcpyDeviceToHost, s));
+    if (no_speech_out) HIP_CHECK(hipMemcpyAsync(no_speech_out, st->nosp_prob.p, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (logprobs_out)
+      for (int b = 0; b < batch; ++b) logprobs_out[b] = lps[(size_t)b * (st->max_tokens + 1) + n_hist[b]];
   });
 }
 

@@ -98,10 +98,15 @@ struct SamplerParams {
   int32_t suppress_blank, no_timestamps, max_initial_ts, n_max, force_len, n_text_ctx;
   int32_t advance;       // 1: n_past[b] += 1 first (a single-token step ran since the last call)
   // the row is scanned by SAMPLER_SPLIT workgroups per window; the one that draws the last ticket merges the partials
-  float* partials;       // [batch][SAMPLER_SPLIT][8]
+  float* partials;       // [batch][SAMPLER_SPLIT][SAMPLER_PART_WORDS]
   unsigned* tickets;     // [batch], zero between launches (re-armed by the kernel)
+  const float* bias;     // [n_vocab] added to every logit before the filter, or null (ohw_state_set_logit_bias)
+  float* tok_lp;         // [batch][max_tokens + 1] log-probability of every sampled token; the end-of-text token's goes
+                         //   to slot n_cur without being counted (whisper.cpp sums it into avg_logprobs), or null
+  float* nosp_prob;      // [batch] softmax probability of the no-speech token in the window's first, unfiltered row, or null
 };
 constexpr int SAMPLER_SPLIT = 8;
+constexpr int SAMPLER_PART_WORDS = 12;
 void launch_sampler(const SamplerParams& p, hipStream_t s);
 
 }  // namespace ohw

@@ -64,6 +64,11 @@ class PreprocessConfig(C.Structure):
                 ("limiter_enabled", C.c_int32), ("limiter_ceiling_db", C.c_float), ("limiter_release_ms", C.c_float)]
 
 
+class GreedyResult(C.Structure):
+    _fields_ = [("tokens", C.POINTER(C.c_int32)), ("n_tokens", C.POINTER(C.c_int32)), ("sum_logprob", C.POINTER(C.c_float)),
+                ("token_logprobs", C.POINTER(C.c_float)), ("ended_by_eot", C.POINTER(C.c_int32)), ("no_speech_prob", C.POINTER(C.c_float))]
+
+
 class WindowQuality(C.Structure):
     _fields_ = [("n_tokens", C.c_int32), ("avg_logprob", C.c_float), ("entropy", C.c_float), ("would_fallback", C.c_int32)]
 
@@ -86,6 +91,7 @@ EXPORTS = [
     "ohw_ctx_create_shell", "ohw_ctx_blob_size", "ohw_ctx_blob_export", "ohw_ctx_blob_import",
     "ohw_default_preprocess_config", "ohw_preprocess_audio", "ohw_dsp_rms_db", "ohw_dsp_apply_gain", "ohw_dsp_normalize_rms",
     "ohw_dsp_compress", "ohw_dsp_limit", "ohw_dsp_resample_linear",
+    "ohw_greedy_ex", "ohw_state_set_logit_bias", "ohw_dbg_sample",
 ]
 
 
@@ -175,6 +181,9 @@ def lib():
         L.ohw_default_sample_params.restype = None
         L.ohw_sample_greedy_host.argtypes = [vp, C.POINTER(SampleParams), fp, ip, C.c_int, fp]
         L.ohw_greedy.argtypes = [vp, C.POINTER(SampleParams), C.c_int, ip, ip, C.c_int, fp]
+        L.ohw_greedy_ex.argtypes = [vp, C.POINTER(SampleParams), C.c_int, C.c_int, C.POINTER(GreedyResult)]
+        L.ohw_state_set_logit_bias.argtypes = [vp, fp, C.c_int]
+        L.ohw_dbg_sample.argtypes = [vp, C.POINTER(SampleParams), fp, ip, C.c_int, ip, C.c_int, ip, fp, fp]
         L.ohw_state_timings.argtypes = [vp, C.POINTER(Timings)]
         L.ohw_engine_new.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.ohw_engine_transcribe.argtypes = [vp, fp, C.c_int64, C.c_uint32, C.c_char_p, C.c_size_t, C.c_char_p,
@@ -422,6 +431,45 @@ class State:
         slp = np.zeros(batch, dtype=np.float32)
         _check(lib().ohw_greedy(self.h, C.byref(p), batch, _ip(toks), _ip(nt), cap, _fp(slp)))
         return [[int(x) for x in toks[b, :nt[b]]] for b in range(batch)], slp
+
+    def greedy_ex(self, batch: int, p: Optional[SampleParams] = None):
+        """ohw_greedy_ex -> list of dict(tokens, logprobs [n (+1 with the end-of-text token's)], ended_by_eot, no_speech_prob)"""
+        p = p or self.ctx.default_params()
+        cap = self.ctx.hp.n_text_ctx
+        toks = np.zeros((batch, cap), dtype=np.int32)
+        nt = np.zeros(batch, dtype=np.int32)
+        slp = np.zeros(batch, dtype=np.float32)
+        lps = np.zeros((batch, cap + 1), dtype=np.float32)
+        eot = np.zeros(batch, dtype=np.int32)
+        nsp = np.zeros(batch, dtype=np.float32)
+        r = GreedyResult(_ip(toks), _ip(nt), _fp(slp), _fp(lps), _ip(eot), _fp(nsp))
+        _check(lib().ohw_greedy_ex(self.h, C.byref(p), batch, cap, C.byref(r)))
+        return [{"tokens": [int(x) for x in toks[b, :nt[b]]], "logprobs": lps[b, :nt[b] + (1 if eot[b] else 0)].copy(),
+                 "ended_by_eot": bool(eot[b]), "no_speech_prob": float(nsp[b]), "sum_logprob": float(slp[b])} for b in range(batch)]
+
+    def set_logit_bias(self, bias: Optional[np.ndarray]):
+        """additive bias [n_vocab] on every logits row before the filter (None clears it)"""
+        if bias is None:
+            _check(lib().ohw_state_set_logit_bias(self.h, C.cast(None, C.POINTER(C.c_float)), 0))
+        else:
+            b = np.ascontiguousarray(bias, dtype=np.float32)
+            _check(lib().ohw_state_set_logit_bias(self.h, _fp(b), b.size))
+
+    def dbg_sample(self, p: SampleParams, logits: np.ndarray, histories: Sequence[Sequence[int]]):
+        """the DEVICE sampler on caller-supplied rows -> (tokens [B], logprobs [B], no_speech_prob [B])"""
+        lg = np.ascontiguousarray(np.atleast_2d(logits), dtype=np.float32)
+        B = lg.shape[0]
+        stride = max(1, max(len(h) for h in histories))
+        hist = np.zeros((B, stride), dtype=np.int32)
+        nh = np.zeros(B, dtype=np.int32)
+        for b, h in enumerate(histories):
+            hist[b, :len(h)] = h
+            nh[b] = len(h)
+        tok = np.zeros(B, dtype=np.int32)
+        lp = np.zeros(B, dtype=np.float32)
+        ns = np.zeros(B, dtype=np.float32)
+        _check(lib().ohw_dbg_sample(self.h, C.byref(p), _fp(lg), _ip(hist), stride, _ip(nh), B, _ip(tok), _fp(lp), _fp(ns)))
+        return tok, lp, ns
 
     def greedy_host_sampler(self, batch: int, p: Optional[SampleParams] = None):
         """the same loop with the HOST owning the sampler: logits cross PCIe every step"""

@@ -49,15 +49,37 @@ def write_synthetic_model(path: str, hp: synth.HParams, seed: int = 1234) -> Non
         for w in vocab:
             f.write(struct.pack("<I", len(w)))
             f.write(w)
-        for spec, arr in synth.iter_tensors(seed, hp):
-            name = spec.name.encode("ascii")
+        # the generator is element-wise numpy (the GIL is released inside it): tensors are made by a few threads, a
+        # bounded number ahead of the writer, and written in the file's order (large-v3 = 3.1 GB: 90 s -> 15 s)
+        import concurrent.futures as cf
+        specs = synth.tensor_specs(hp)
+
+        def make(spec):
             as_f16 = spec.f16 and hp.ftype == 1
-            dims = list(reversed(spec.shape))
-            f.write(struct.pack("<3i", len(dims), len(name), 1 if as_f16 else 0))
-            f.write(struct.pack("<%di" % len(dims), *dims))
-            f.write(name)
-            f.write(arr.astype("<f2" if as_f16 else "<f4").tobytes())
+            return synth.gen_tensor(seed, spec, hp).astype("<f2" if as_f16 else "<f4"), as_f16
+
+        workers = max(1, min(8, len(os.sched_getaffinity(0))))
+        with cf.ThreadPoolExecutor(max_workers=workers) as ex:
+            pending = []
+            it = iter(specs)
+            for spec in it:
+                pending.append((spec, ex.submit(make, spec)))
+                if len(pending) < 2 * workers:
+                    continue
+                _write_tensor(f, *pending.pop(0))
+            while pending:
+                _write_tensor(f, *pending.pop(0))
     os.replace(tmp, path)
+
+
+def _write_tensor(f, spec, fut) -> None:
+    arr, as_f16 = fut.result()
+    name = spec.name.encode("ascii")
+    dims = list(reversed(spec.shape))
+    f.write(struct.pack("<3i", len(dims), len(name), 1 if as_f16 else 0))
+    f.write(struct.pack("<%di" % len(dims), *dims))
+    f.write(name)
+    f.write(arr.tobytes() if arr.size < (1 << 20) else memoryview(arr).cast("B"))
 
 
 def read_model(path: str) -> Tuple[synth.HParams, np.ndarray, List[bytes], Dict[str, np.ndarray]]:

@@ -108,17 +108,31 @@ def load_model_broadcast(model_path: str, dist, world: int, rank: int, device_in
     (SURVEY.md 8e).  The hyper-parameters travel first (11 ints).  via_host=True stages through host memory (gloo)."""
     from . import engine as E
     dev = torch.device("cuda", device_index)
-    hp_t = torch.zeros(11, dtype=torch.int32)
+    # word 0 = status of rank 0's load (0 ok, else the library's error code), then the 11 hyper-parameters: every rank
+    # learns of a failed load in the same broadcast and raises, instead of waiting in the blob broadcast for the timeout
+    hp_t = torch.zeros(12, dtype=torch.int32)
     ctx = None
+    err = None
     if rank == 0:
-        ctx = E.Context.from_file(model_path, device_index, dtype)
-        hp_t = torch.tensor(ctx.hp.as_list(), dtype=torch.int32)
+        try:
+            ctx = E.Context.from_file(model_path, device_index, dtype)
+            hp_t[1:] = torch.tensor(ctx.hp.as_list(), dtype=torch.int32)
+        except E.WhisperError as ex:
+            err = ex
+            hp_t[0] = int(ex.code) if ex.code else -1
     if world == 1:
+        if err is not None:
+            raise err
         return ctx
     hp_t = hp_t if via_host else hp_t.to(dev)
     dist.broadcast(hp_t, src=0)
+    status = int(hp_t[0])
+    if status != 0:
+        if err is not None:
+            raise err
+        raise E.LoadFailed(status, f"rank 0 could not load {model_path} (code {status})")
     if rank != 0:
-        ctx = E.Context.shell([int(v) for v in hp_t.cpu()], device_index, dtype)
+        ctx = E.Context.shell([int(v) for v in hp_t.cpu()[1:]], device_index, dtype)
     n = ctx.blob_size()
     blob = torch.empty(n, dtype=torch.uint8, device=dev)
     if rank == 0:

@@ -54,6 +54,7 @@ def lib():
         L.ref_model_synth.restype = C.c_void_p
         L.ref_model_synth.argtypes = [ip, C.c_uint32]
         L.ref_model_free.argtypes = [C.c_void_p]
+        L.ref_model_save.argtypes = [C.c_void_p, C.c_char_p]
         L.ref_model_hparams.argtypes = [C.c_void_p, ip]
         L.ref_model_mel_filters.restype = fp
         L.ref_model_mel_filters.argtypes = [C.c_void_p]
@@ -80,6 +81,8 @@ def lib():
         L.ref_build_prompt.argtypes = [C.c_void_p, C.POINTER(SampleParams), ip]
         L.ref_process_logits.argtypes = [C.c_void_p, C.POINTER(SampleParams), fp, ip, C.c_int, fp, fp]
         L.ref_greedy.argtypes = [C.c_void_p, C.POINTER(SampleParams), ip, fp, fp, fp]
+        L.ref_process_logits_ex.argtypes = [C.c_void_p, C.POINTER(SampleParams), fp, ip, C.c_int, fp, C.c_float, fp, fp, fp]
+        L.ref_greedy_ex.argtypes = [C.c_void_p, C.POINTER(SampleParams), fp, ip, C.c_int, ip, fp, fp, ip, ip, fp]
         L.ref_transcribe_chunk.argtypes = [C.c_void_p, fp, C.c_int64, C.c_int, C.POINTER(SampleParams), ip,
                                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ref_num_threads.restype = C.c_int
@@ -129,6 +132,11 @@ class Model:
     def synth(cls, hparams_list: List[int], seed: int = 1234) -> "Model":
         hp = np.asarray(hparams_list, dtype=np.int32)
         return cls(lib().ref_model_synth(_ip(hp), seed))
+
+    def save(self, path: str) -> None:
+        """write the model as a ggml file (the format Model.load and libohw read)"""
+        if lib().ref_model_save(self.h, path.encode()) != 0:
+            raise OSError(f"oracle: cannot write {path}")
 
     def close(self):
         if self.h:
@@ -194,6 +202,17 @@ class Model:
         tok = lib().ref_process_logits(self.h, C.byref(p), _fp(lg), _ip(c), len(cur), _fp(lps), C.byref(lp))
         return int(tok), float(lp.value), lg, lps
 
+    def process_logits_ex(self, p: SampleParams, logits: np.ndarray, cur: List[int], bias: Optional[np.ndarray] = None,
+                          temperature: float = 0.0):
+        """(token, logprob_of_token, no_speech_prob or None) with the additive bias / temperature applied first"""
+        lg = np.ascontiguousarray(logits, dtype=np.float32).copy()
+        c = np.asarray(cur if len(cur) else [0], dtype=np.int32)
+        lp, ns = C.c_float(0), C.c_float(-1.0)
+        nul = C.cast(None, C.POINTER(C.c_float))
+        bp = _fp(np.ascontiguousarray(bias, dtype=np.float32)) if bias is not None else nul
+        tok = lib().ref_process_logits_ex(self.h, C.byref(p), _fp(lg), _ip(c), len(cur), bp, temperature, nul, C.byref(lp), C.byref(ns))
+        return int(tok), float(lp.value), (float(ns.value) if len(cur) == 0 else None)
+
     def transcribe_chunk(self, pcm: np.ndarray, p: Optional[SampleParams] = None, mel_mode: int = 0):
         """(tokens, (t_mel, t_enc, t_dec)) — the timed CPU baseline path"""
         p = p or self.default_params()
@@ -250,6 +269,33 @@ class State:
         avg = C.c_float(0)
         n = lib().ref_greedy(self.h, C.byref(p), _ip(out), _fp(lps), _fp(mg), C.byref(avg))
         return [int(x) for x in out[:n]], lps[:n].copy(), mg[:n + 1].copy(), float(avg.value)
+
+
+def _state_greedy_ex(self, p: Optional[SampleParams] = None, bias: Optional[np.ndarray] = None, forced: Optional[List[int]] = None):
+    """dict(tokens, logprobs [n (+1 when ended_by_eot)], margins [steps], choice [steps], ended_by_eot, no_speech_prob).
+    With `forced` the walk follows those tokens (an end-of-text entry ends it) while the oracle's own pick and top-2
+    margin are recorded at every step."""
+    p = p or self.m.default_params()
+    cap = self.m.n_text_ctx + 1
+    out = np.zeros(cap, dtype=np.int32)
+    lps = np.zeros(cap, dtype=np.float32)
+    mg = np.zeros(cap, dtype=np.float32)
+    ch = np.full(cap, -1, dtype=np.int32)
+    eot, ns = C.c_int32(0), C.c_float(0)
+    nul = C.cast(None, C.POINTER(C.c_float))
+    bp = _fp(np.ascontiguousarray(bias, dtype=np.float32)) if bias is not None else nul
+    f = np.asarray(forced, dtype=np.int32) if forced is not None and len(forced) else None
+    fptr = _ip(f) if f is not None else C.cast(None, C.POINTER(C.c_int32))
+    nf = len(f) if f is not None else 0
+    if forced is not None and f is None:
+        f = np.zeros(1, np.int32); fptr = _ip(f)      # forced = []: one recorded step, nothing consumed
+    n = lib().ref_greedy_ex(self.h, C.byref(p), bp, fptr, nf, _ip(out), _fp(lps), _fp(mg), _ip(ch), C.byref(eot), C.byref(ns))
+    steps = int((ch >= 0).sum())
+    return {"tokens": [int(x) for x in out[:n]], "logprobs": lps[:n + (1 if eot.value else 0)].copy(), "margins": mg[:steps].copy(),
+            "choice": [int(x) for x in ch[:steps]], "ended_by_eot": bool(eot.value), "no_speech_prob": float(ns.value)}
+
+
+State.greedy_ex = _state_greedy_ex
 
 
 def num_threads() -> int:

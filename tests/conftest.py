@@ -25,7 +25,15 @@ def tmp_models(tmp_path_factory):
         key = (preset, seed)
         if key not in cache:
             path = os.path.join(str(d), f"ggml-{preset}-s{seed}.bin")
-            modelfile.write_synthetic_model(path, synth.PRESETS[preset], seed)
+            if synth.PRESETS[preset].n_audio_state >= 1024:
+                # medium / large-v3: gigabytes - the oracle's OpenMP generator (proven identical to synth.py tensor by
+                # tensor, test_oracle_golden.py) writes the same file in seconds
+                from oracle import oracle
+                om = oracle.Model.synth(synth.PRESETS[preset].as_list(), seed)
+                om.save(path)
+                om.close()
+            else:
+                modelfile.write_synthetic_model(path, synth.PRESETS[preset], seed)
             cache[key] = path
         return cache[key]
 

@@ -19,7 +19,7 @@ done
 echo "[profiles] pmc sq"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 1 --warmup 0 --tokens 6 --no-cpu-baseline > $O/pmc_sq.log 2>&1
 # the per-dispatch CSVs (> 100 MB) cannot travel back (64 MiB limit): summarise here, keep only the summaries
-TAG=${1:-r01}
+TAG=${1:-r02}
 python3 tools/summarize_profiles.py $TAG $O/profiles_out > $O/profiles_out.log 2>&1
 cp $O/bench_final.json $O/profiles_out/${TAG}_bench_large-v3_b32.json
 cp $O/bench_f16.json $O/profiles_out/${TAG}_bench_large-v3_b32_f16.json

@@ -14,7 +14,7 @@ import shutil
 import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 # on the GPU box the raw per-dispatch CSVs (> 100 MB) cannot travel back: tools/run_profiles.sh summarises there, into
 # gpurun_out/profiles_out/, and the files are then copied to profiles/ here
 P = sys.argv[2] if len(sys.argv) > 2 else f"{R}/profiles"
@@ -59,11 +59,16 @@ for key in sorted(fe, key=lambda k: -sum(x[0] for x in fe[k]["FETCH_SIZE"])):
     gui = (sum(x[0] for x in g["GRBM_GUI_ACTIVE"]) / len(g["GRBM_GUI_ACTIVE"])) if "GRBM_GUI_ACTIVE" in g else 0.0
     dur = (sum(x[1] for x in g["GRBM_GUI_ACTIVE"]) / len(g["GRBM_GUI_ACTIVE"])) if "GRBM_GUI_ACTIVE" in g else 0.0
     cyc = gui / 8.0
+    # GRBM_GUI_ACTIVE / duration reads high on short dispatches (MI355X_MICROARCH.md "DVFS give-back": the quotient is
+    # only meaningful from about 0.3 ms; round 1's table showed 4-13 GHz for sub-10 us kernels): the clock and the MFMA-busy
+    # fraction derived from it are left empty below 20 us
+    short = dur < 20e3
     clock = cyc / dur if dur > 0 else 0.0
     mfma = avg("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * cyc) if cyc > 0 else 0.0
     wc = avg("SQ_WAVE_CYCLES") or 1.0
-    lines.append('"%s",%d,%d,%.1f,%.2f,%.3f,%.4g,%.4g,%.3f,%.3f,%.3f,%.3f,%.3f,%.4g' % (
-        k, wg, n, sum(f) / n, 2 * sum(f) / n / 1024, sum(w) / len(w) / 1024, avg("SQ_VALU_MFMA_BUSY_CYCLES"), gui, clock, mfma,
+    lines.append('"%s",%d,%d,%.1f,%.2f,%.3f,%.4g,%.4g,%s,%s,%.3f,%.3f,%.3f,%.4g' % (
+        k, wg, n, sum(f) / n, 2 * sum(f) / n / 1024, sum(w) / len(w) / 1024, avg("SQ_VALU_MFMA_BUSY_CYCLES"), gui,
+        "n/a(<20us)" if short else "%.3f" % clock, "n/a(<20us)" if short else "%.3f" % mfma,
         avg("SQ_WAIT_ANY") / wc, avg("SQ_WAIT_INST_ANY") / wc, avg("SQ_ACTIVE_INST_ANY") / wc, avg("SQ_LDS_BANK_CONFLICT")))
     if "cross_attn" in k and wg == 640:
         out["3"] = {"kernel": "cross_attn_kernel", "batch": 32, "hbm_bytes_per_launch": int(2 * sum(f) / n * 1024 + sum(w) / len(w) * 1024),
