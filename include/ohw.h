@@ -150,6 +150,11 @@ int ohw_encode(ohw_state* st, int batch);
 /* feed tokens[b][0..n_new) at positions n_past[b].. and return logits of the last fed position    */
 /* per window: logits_out [batch][n_vocab] f32 (host).  tokens: [batch][n_new] row-major.          */
 int ohw_decode(ohw_state* st, const int32_t* tokens, int n_new, const int32_t* n_past, int batch, float* logits_out);
+/* the same for a SUBSET of the batch: windows with active[b] == 0 ride along (their rows of the weight-streaming GEMMs cost
+ * nothing) but their cross K/V is not streamed and their logits row is not copied.  What the temperature fallback uses to
+ * re-decode only the windows that failed, on their resident cross K/V.  active == NULL: every window.              */
+int ohw_decode_active(ohw_state* st, const int32_t* tokens, int n_new, const int32_t* n_past, int batch, const int32_t* active,
+                      float* logits_out);
 
 /* language identification for the windows of the last ohw_encode (whisper.cpp whisper_lang_auto_detect: one
  * decoder step on [sot], soft-max over the language tokens only).  lang_ids_out [batch];
@@ -174,6 +179,17 @@ void ohw_default_sample_params(const ohw_ctx* ctx, ohw_sample_params* p);
 /* logits: [n_vocab], modified in place; cur: tokens sampled so far in this window.               */
 int32_t ohw_sample_greedy_host(const ohw_ctx* ctx, const ohw_sample_params* p, float* logits,
                                const int32_t* cur, int n_cur, float* logprob_out);
+
+/* the host sampler at a temperature: whisper.cpp's whisper_sample_token(best = false) - logits / temperature, the same
+ * filter, then one draw of std::discrete_distribution over exp(logprobs) from a std::mt19937 (whisper.cpp seeds each
+ * decoder's generator with 0 once per whisper_full call).  temperature <= 0: arg-max (rng may be NULL).
+ * no_speech_prob_out (may be NULL) is written on a window's first step (n_cur == 0): soft-max probability of the
+ * no-speech token in the scaled, unfiltered row.                                                                    */
+typedef struct ohw_rng ohw_rng;
+ohw_rng* ohw_rng_new(uint32_t seed);
+void ohw_rng_free(ohw_rng* rng);
+int32_t ohw_sample_host(const ohw_ctx* ctx, const ohw_sample_params* p, float* logits, const int32_t* cur, int n_cur,
+                        float temperature, ohw_rng* rng, float* logprob_out, float* no_speech_prob_out);
 
 /* device-resident greedy loop for the windows of the last ohw_encode: prompt, KV-cached steps,   */
 /* logits filter and arg-max all stay on the GPU; only token ids come back.                        */
@@ -229,12 +245,38 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
 /* full text of the last transcribe (owned by the engine until the next call): a 2 h file can exceed any   */
 /* fixed text_buf; text_buf receives a truncated copy, this returns everything.                              */
 int ohw_engine_last_text(ohw_engine* e, const char** text, size_t* len);
-/* Decode quality of every window of the last transcribe, with whisper.cpp's fallback criteria (SURVEY.md A4.6,
- * Appendix A: entropy_thold 2.4 over the last 32 tokens, logprob_thold -1.0).  whisper.cpp would re-decode a
- * window that fails them at temperature 0.2, 0.4 ... with its own RNG stream; this engine stays greedy (T = 0,
- * what `Greedy{best_of:1}` asks for first) and reports `would_fallback` instead of sampling. */
-typedef struct { int32_t n_tokens; float avg_logprob; float entropy; int32_t would_fallback; } ohw_window_quality;
+/* whisper.cpp's per-window decode policy, which the reference inherits because it sets none of these
+ * (reference src/engine/whisper.rs:243-263 -> whisper_full_default_params; recalled from
+ * upstream, unpinned):
+ *   - exits of the decode loop: end-of-text; a timestamp that leaves less than 1 s of audio; failure when the loop
+ *     reaches n_max without a timestamp past the middle of the window (the repetition guard) or when end-of-text comes
+ *     with no timestamp while audio is left;
+ *   - acceptance: not failed, token-frequency entropy of the last 32 tokens >= entropy_thold, and not
+ *     (avg_logprob < logprob_thold while no_speech_prob < no_speech_thold); a pass that is not accepted is decoded again
+ *     at temperature += temperature_inc (up to 1.0), sampled on the host with std::mt19937(0) + std::discrete_distribution
+ *     on the window's resident cross K/V (ohw_decode_active); the last temperature is accepted whatever it gives;
+ *   - no speech: a window with no_speech_prob > no_speech_thold and avg_logprob < logprob_thold yields no text.
+ * temperature_inc <= 0 keeps every window at T = 0 (what bench.py times: SURVEY.md 8d). */
+typedef struct { float temperature_inc, entropy_thold, logprob_thold, no_speech_thold; } ohw_decode_policy;
+void ohw_default_decode_policy(ohw_decode_policy* q);   /* 0.2, 2.4, -1.0, 0.6 */
+int ohw_engine_set_decode_policy(ohw_engine* e, const ohw_decode_policy* q);
+/* per window of the last transcribe, for the pass that was kept */
+typedef struct {
+  int32_t n_tokens;        /* tokens that reached the text / ohw_engine_last_tokens (0 for a no-speech window) */
+  float avg_logprob;       /* over the first result_len tokens (whisper.cpp avg_logprobs; -inf when result_len == 0) */
+  float entropy;           /* of the last 32 of them */
+  int32_t would_fallback;  /* the T = 0 pass failed the acceptance test */
+  float temperature;       /* of the kept pass */
+  float no_speech_prob;
+  int32_t no_speech;       /* dropped by the no-speech rule */
+  int32_t seek_delta;      /* 10 ms frames the window covers: 3000 unless a timestamp ended it (what the seek loop advances by) */
+  int32_t result_len;      /* whisper.cpp result_len: tokens up to and including the last timestamp */
+  int32_t failed;          /* the kept pass ended in one of the loop's failure exits */
+} ohw_window_quality;
 int ohw_engine_last_quality(ohw_engine* e, const ohw_window_quality** q, int* n_windows);
+/* every decode pass of the last transcribe, flat: {window index, temperature * 1000, n, n sampled tokens
+ * (end-of-text included when it was sampled)} repeated - what a parity check walks pass by pass */
+int ohw_engine_last_trace(ohw_engine* e, const int32_t** data, int* n);
 /* How audio longer than 30 s is windowed.  FIXED (default): host-side cuts every 30 s, windows batched
  * (BASELINE.json north_star).  SEEK: whisper.cpp's sequential loop as recalled (unpinned): the
  * next window starts at the last timestamp token of the previous one (seek += 2 * (ts - ts_begin) frames of

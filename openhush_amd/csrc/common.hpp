@@ -14,6 +14,25 @@
 
 namespace ohw {
 
+// Process-wide gate around stream capture.  While ANY stream of the process captures, HIP (ROCm 7.2) rejects what other
+// threads do in the meantime - a kernel launch on a CU-masked (blocking) stream, a synchronous hipMemset - with
+// "operation would make the legacy stream depend on a capturing blocking stream", and that error also invalidates the
+// capture.  Two engines driven by two threads hit it (tests/test_gpu_configs.py).  Every C-ABI entry that touches the
+// device holds the gate shared (outermost call of the thread only: entries nest); the one place that captures a graph -
+// once per (state, batch, sampler parameters) - takes it exclusively for the few milliseconds the capture lasts.
+struct ApiScope {
+  ApiScope();
+  ~ApiScope();
+  ApiScope(const ApiScope&) = delete;
+  ApiScope& operator=(const ApiScope&) = delete;
+};
+struct CaptureGate {   // inside an ApiScope: shared -> exclusive for the lifetime of the object
+  CaptureGate();
+  ~CaptureGate();
+  CaptureGate(const CaptureGate&) = delete;
+  CaptureGate& operator=(const CaptureGate&) = delete;
+};
+
 struct Error : std::runtime_error {
   int code;
   Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}

@@ -138,30 +138,44 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
     // every load is unconditional (clamped column, masked value): a per-element "load or zero" branch
     // makes hipcc wait vmcnt(0) per element and serialises 20 L2 round trips
     f32x4 v[NV];
-    float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * TPR + sub) * 4;
       const int cc = c < p.K ? c : 0;
       v[i] = *(const f32x4*)(xr + cc);
     }
+    // The row statistics must not depend on MT (which follows the CU budget of the stream: a decode on a CU-masked
+    // stream has to give the tokens of the same decode on the whole chip, bit for bit).  The sum is DEFINED as that of
+    // 32 "virtual" threads per row - virtual thread s adds the float4 groups s, s + 32, s + 64 ... in order - followed
+    // by the xor tree 16, 8, 4, 2, 1.  With 16 threads per row (MT = 2) a thread plays the virtual threads `sub` (its
+    // even groups) and `sub + 16` (its odd groups) and adds the two: the tree's first level.
+    constexpr int VS = 32 / TPR;                 // virtual threads per physical thread: 1 or 2
+    float sv[VS];
+#pragma unroll
+    for (int q = 0; q < VS; ++q) sv[q] = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * TPR + sub) * 4;
       const float ok = c < p.K ? 1.f : 0.f;
-      sum += ok * ((v[i].x + v[i].y) + (v[i].z + v[i].w));
+      sv[i % VS] += ok * ((v[i].x + v[i].y) + (v[i].z + v[i].w));
     }
+    float sum = sv[0];
+    if constexpr (VS == 2) sum += sv[1];
 #pragma unroll
     for (int o = TPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float mean = sum / (float)p.K;
-    float var = 0.f;
+    float vv[VS];
+#pragma unroll
+    for (int q = 0; q < VS; ++q) vv[q] = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * TPR + sub) * 4;
       const float ok = c < p.K ? 1.f : 0.f;
       const float a = v[i].x - mean, b2 = v[i].y - mean, c2 = v[i].z - mean, d2 = v[i].w - mean;
-      var += ok * ((a * a + b2 * b2) + (c2 * c2 + d2 * d2));
+      vv[i % VS] += ok * ((a * a + b2 * b2) + (c2 * c2 + d2 * d2));
     }
+    float var = vv[0];
+    if constexpr (VS == 2) var += vv[1];
 #pragma unroll
     for (int o = TPR / 2; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
     const float rstd = rsqrtf(var / (float)p.K + 1e-5f);

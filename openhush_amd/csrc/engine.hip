@@ -6,6 +6,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <type_traits>
 #include <vector>
 #include <algorithm>
@@ -22,8 +23,16 @@ ohw_ctx* ctx_shell(const ohw_hparams* hp, int device, int dtype);
 
 thread_local std::string g_last_error;
 
+static std::shared_mutex g_api_mu;
+static thread_local int g_api_depth = 0;
+ApiScope::ApiScope() { if (g_api_depth++ == 0) g_api_mu.lock_shared(); }
+ApiScope::~ApiScope() { if (--g_api_depth == 0) g_api_mu.unlock_shared(); }
+CaptureGate::CaptureGate() { g_api_mu.unlock_shared(); g_api_mu.lock(); }
+CaptureGate::~CaptureGate() { g_api_mu.unlock(); g_api_mu.lock_shared(); }
+
 template <typename F>
 static int guard(F&& f) {
+  ApiScope api;
   try {
     f();
     return OHW_OK;
@@ -399,6 +408,7 @@ int ohw_token_text(const ohw_ctx* ctx, int32_t id, const char** text) {
 
 void ohw_ctx_free(ohw_ctx* ctx) {
   if (!ctx) return;
+  ApiScope api;
   (void)hipSetDevice(ctx->device);
   delete ctx;
 }
@@ -422,6 +432,7 @@ int ohw_state_create(ohw_ctx* ctx, int max_batch, ohw_state** out) {
 
 void ohw_state_free(ohw_state* st) {
   if (!st) return;
+  ApiScope api;
   (void)hipSetDevice(st->ctx->device);
   (void)hipDeviceSynchronize();
   for (auto& e : st->ev) if (e) (void)hipEventDestroy(e);
@@ -552,7 +563,8 @@ int ohw_encode(ohw_state* st, int batch) {
   });
 }
 
-int ohw_decode(ohw_state* st, const int32_t* tokens, int n_new, const int32_t* n_past, int batch, float* logits_out) {
+int ohw_decode_active(ohw_state* st, const int32_t* tokens, int n_new, const int32_t* n_past, int batch, const int32_t* active,
+                      float* logits_out) {
   return guard([&] {
     if (!st || !tokens || !n_past) throw Error(OHW_E_INVALID_ARG, "null argument");
     if (batch < 1 || batch != st->enc_batch) throw Error(OHW_E_INVALID_ARG, "decode: batch must equal the batch of the last ohw_encode");
@@ -567,15 +579,36 @@ int ohw_decode(ohw_state* st, const int32_t* tokens, int n_new, const int32_t* n
     hipStream_t s = st->stream;
     HIP_CHECK(hipMemcpyAsync(st->step_tok.p, tokens, (size_t)batch * n_new * 4, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(st->n_past.p, n_past, (size_t)batch * 4, hipMemcpyHostToDevice, s));
+    // inactive windows ride along (their GEMM rows are free) but their cross K/V is not streamed: the done flags the
+    // greedy loop uses for finished windows
+    std::vector<int32_t> skip;
+    struct SkipDone { bool& f; bool on; SkipDone(bool& r, bool o) : f(r), on(o) { if (on) f = true; } ~SkipDone() { if (on) f = false; } } skip_done(st->skip_done, active != nullptr);
+    if (active) {
+      skip.resize((size_t)batch);
+      for (int b = 0; b < batch; ++b) skip[(size_t)b] = active[b] ? 0 : 1;
+      HIP_CHECK(hipMemcpyAsync(st->done.p, skip.data(), skip.size() * 4, hipMemcpyHostToDevice, s));
+    }
     Dispatch::run(st->ctx->dtype, [&](auto* tag) {
       using T = std::remove_pointer_t<decltype(tag)>;
       run_decoder_step<T>(st, batch, n_new);
     });
-    if (logits_out)
-      HIP_CHECK(hipMemcpy2DAsync(logits_out, (size_t)hp.n_vocab * 4, st->logits.p, (size_t)st->logits_ld * 4, (size_t)hp.n_vocab * 4,
-                                 (size_t)batch, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    if (logits_out) {
+      if (!active) {
+        HIP_CHECK(hipMemcpy2DAsync(logits_out, (size_t)hp.n_vocab * 4, st->logits.p, (size_t)st->logits_ld * 4, (size_t)hp.n_vocab * 4,
+                                   (size_t)batch, hipMemcpyDeviceToHost, s));
+      } else {
+        for (int b = 0; b < batch; ++b)
+          if (active[b])
+            HIP_CHECK(hipMemcpyAsync(logits_out + (size_t)b * hp.n_vocab, st->logits.as<float>() + (size_t)b * st->logits_ld, (size_t)hp.n_vocab * 4,
+                                     hipMemcpyDeviceToHost, s));
+      }
+    }
+    HIP_CHECK(hipStreamSynchronize(s));   // also keeps `skip` alive until its copy has run
   });
+}
+
+int ohw_decode(ohw_state* st, const int32_t* tokens, int n_new, const int32_t* n_past, int batch, float* logits_out) {
+  return ohw_decode_active(st, tokens, n_new, n_past, batch, nullptr, logits_out);
 }
 
 void ohw_default_sample_params(const ohw_ctx* ctx, ohw_sample_params* p) {
@@ -646,17 +679,29 @@ int ohw_greedy_ex(ohw_state* st, const ohw_sample_params* sp, int batch, int max
           st->step_graphs.erase(st->step_graphs.begin());
         }
         ohw_state::StepGraph ng;
-        HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        // The iteration is captured on the state's OWN stream (non-blocking) and replayed on whatever stream the state
+        // runs on: a CU-masked stream (hipExtStreamCreateWithCUMask) is a blocking stream, and while a blocking stream
+        // captures, any use of the legacy stream by another thread - another engine loading its model, say - fails with
+        // "would make the legacy stream depend on a capturing blocking stream" and kills the capture (two engines driven
+        // by two threads: tests/test_gpu_configs.py).  The own stream is idle whenever the state runs on an external one.
+        // Capture mode RELAXED: in the other modes HIP (ROCm 7.2) rejects every synchronous memory call of EVERY thread
+        // while a capture is open - hipMemset in another engine's state allocation failed that way - and this thread
+        // makes no call during the capture that the stricter modes would have to catch.
+        hipStream_t cap = st->own_stream;
+        CaptureGate gate;   // no other thread is inside the library while this stream captures (common.hpp)
+        struct StreamSwap { ohw_state* st; hipStream_t keep; ~StreamSwap() { st->stream = keep; } } swap{st, st->stream};
+        st->stream = cap;
+        HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
         try {
           run_decoder_step<T>(st, batch, 1, st->next_tok.as<int32_t>());   // the token the sampler just wrote
-          launch_sampler(spar, s);
+          launch_sampler(spar, cap);
         } catch (...) {
           hipGraph_t g = nullptr;
-          (void)hipStreamEndCapture(s, &g);
+          (void)hipStreamEndCapture(cap, &g);
           if (g) (void)hipGraphDestroy(g);
           throw;
         }
-        HIP_CHECK(hipStreamEndCapture(s, &ng.graph));
+        HIP_CHECK(hipStreamEndCapture(cap, &ng.graph));
         hipError_t ie = hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0);
         if (ie != hipSuccess) { (void)hipGraphDestroy(ng.graph); HIP_CHECK(ie); }
         ng.batch = batch; ng.cus = st->stream_cus; ng.spar = spar;

@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <memory>
+#include <random>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -37,6 +38,7 @@ const char* const kLangs[99] = {
 
 template <typename F>
 int guard(F&& f) {
+  ApiScope api;
   try {
     f();
     return OHW_OK;
@@ -69,7 +71,98 @@ struct ohw_engine {
   void* s_full = nullptr; void* s_enc = nullptr; void* s_dec = nullptr;
   int enc_cus = 96;
   int device = 0;
+  ohw_decode_policy policy{0.2f, 2.4f, -1.0f, 0.6f};
+  std::vector<int32_t> last_trace;   // every decode pass of the last transcribe: {window, temperature * 1000, n, tokens...}
 };
+
+namespace {
+// ---- whisper.cpp's per-window bookkeeping (whisper_full_with_state as recalled) ---------
+struct SeqEval {
+  int n_sampled = 0;     // tokens up to and including the one that ended the pass
+  int result_len = 0;    // whisper.cpp result_len: up to and including the last timestamp token (> token_beg)
+  int n_keep = 0;        // tokens that reach the text
+  int seek_delta = 3000; // 10 ms frames the window advances by
+  bool failed = false, completed = false;
+  float avg_logprob = -INFINITY, entropy = 0.f;
+};
+
+// frames of 10 ms whisper.cpp attributes to n samples: mel.n_len_org = 1 + (n + 200 - 400) / 160
+int mel_frames(int64_t n) { return (int)(1 + (n + 200 - 400) / 160); }
+
+// One sampled sequence, judged after the fact (greedy decoding is causal: cutting at the first exit the walk finds equals
+// having stopped there).  tok[0..n): the sampled tokens, the end-of-text token last when it was sampled.
+//   exits      end-of-text; a timestamp that leaves less than 1 s of audio (seek + seek_delta + 100 >= seek_end);
+//              failure when timestamps go back, when end-of-text arrives with no timestamp and audio left, or when the
+//              loop reaches n_max without a timestamp past the middle of the window (the repetition-loop guard)
+//   score      average log-probability and token-frequency entropy of the last 32 of the first result_len tokens
+//   kept       fixed 30 s cuts: everything before the exit (each window is decoded once); seek loop: result_len tokens
+//              (what follows the last timestamp is decoded again by the next window)
+SeqEval evaluate_sequence(const ohw_special_tokens& tk, const int32_t* tok, const float* plog, int n, int seek, int seek_end, int n_max,
+                          bool no_timestamps, int window_mode) {
+  SeqEval r;
+  bool has_ts = false;
+  int stop = n;
+  for (int i = 0; i < n; ++i) {
+    const int t = tok[i];
+    if (t > tk.timestamp_begin) {
+      const int nd = 2 * (t - tk.timestamp_begin);
+      if (has_ts && r.seek_delta > nd && r.result_len < i) { r.failed = true; stop = i + 1; break; }
+      r.seek_delta = nd; r.result_len = i + 1; has_ts = true;
+    }
+    const bool audio_end = seek + r.seek_delta + 100 >= seek_end;
+    if (t == tk.eot || (has_ts && audio_end)) {
+      if (r.result_len == 0 && !no_timestamps) {
+        if (audio_end) r.result_len = i + 1;
+        else { r.failed = true; stop = i + 1; break; }
+      }
+      if (no_timestamps) { r.result_len = i + 1; r.seek_delta = 3000; }
+      r.completed = true; stop = i + 1;
+      break;
+    }
+    if (i == n_max - 1 && (r.result_len == 0 || r.seek_delta < 1500)) { r.failed = true; stop = i + 1; break; }
+  }
+  r.n_sampled = stop;
+  if (r.result_len > 0) {
+    double sum = 0.0;
+    for (int i = 0; i < r.result_len; ++i) sum += plog[i];
+    r.avg_logprob = (float)(sum / r.result_len);
+    const int n32 = std::min(32, r.result_len), i0 = r.result_len - n32;
+    double ent = 0.0;
+    for (int i = i0; i < r.result_len; ++i) {
+      bool first = true;
+      int cnt = 0;
+      for (int j = i0; j < r.result_len; ++j) if (tok[j] == tok[i]) { if (j < i) first = false; ++cnt; }
+      if (first) { const double pr = (double)cnt / n32; ent -= pr * std::log(pr); }
+    }
+    r.entropy = (float)ent;
+  }
+  int keep = r.failed ? stop : (window_mode == OHW_WINDOW_SEEK ? r.result_len : stop);
+  while (keep > 0 && tok[keep - 1] == tk.eot) --keep;
+  r.n_keep = keep;
+  return r;
+}
+
+bool needs_fallback(const SeqEval& r, const ohw_decode_policy& q, float no_speech_prob, bool is_last) {
+  if (is_last) return false;
+  const bool failed = r.failed || r.result_len == 0 || r.entropy < q.entropy_thold;
+  return failed || (r.avg_logprob < q.logprob_thold && no_speech_prob < q.no_speech_thold);
+}
+
+struct WindowRun {
+  std::vector<int32_t> tok;   // sampled tokens of the kept pass (end-of-text last when sampled)
+  std::vector<float> plog;
+  float nosp = 0.f, temp = 0.f;
+  SeqEval ev;
+  bool pending = false, t0_failed = false;
+};
+
+std::vector<float> ladder(const ohw_decode_policy& q) {
+  std::vector<float> t;
+  if (q.temperature_inc > 0.0f)
+    for (float x = q.temperature_inc; x < 1.0f + 1e-6f && t.size() < 16; x += q.temperature_inc) t.push_back(x);
+  return t;
+}
+}  // namespace
 
 extern "C" {
 
@@ -113,11 +206,10 @@ int ohw_validate_audio(const float* samples, int64_t n, uint32_t sample_rate, oh
   return OHW_OK;
 }
 
-// Host-side logits filter + arg-max: whisper.cpp's greedy path with the defaults the reference
-// inherits.  Same rule order as the device sampler in decode.hip.
-int32_t ohw_sample_greedy_host(const ohw_ctx* ctx, const ohw_sample_params* p, float* logits, const int32_t* cur, int n_cur,
-                               float* logprob_out) {
-  if (!ctx || !p || !logits) return -1;
+// Host-side logits filter: whisper.cpp's whisper_process_logits with the defaults the reference inherits
+// (SURVEY.md A4.6, Appendix A).  Same rule order as the device sampler in decode.hip.  Masks `logits` in place
+// (timestamp-mass rule included) and returns the log-sum-exp taken BEFORE that rule, as whisper.cpp's logprobs are.
+static float filter_logits(const ohw_ctx* ctx, const ohw_sample_params* p, float* logits, const int32_t* cur, int n_cur) {
   const ohw_special_tokens& t = ctx->tok;
   const int V = ctx->hp.n_vocab;
   const float NEG = -INFINITY;
@@ -161,11 +253,48 @@ int32_t ohw_sample_greedy_host(const ohw_ctx* ctx, const ohw_sample_params* p, f
     const float ts_lp = mx + (float)std::log(ts_sum) - lse;
     if (ts_lp > text_max - lse) for (int i = 0; i < t.timestamp_begin; ++i) logits[i] = NEG;
   }
+  return lse;
+}
+
+int32_t ohw_sample_greedy_host(const ohw_ctx* ctx, const ohw_sample_params* p, float* logits, const int32_t* cur, int n_cur,
+                               float* logprob_out) {
+  if (!ctx || !p || !logits) return -1;
+  const float lse = filter_logits(ctx, p, logits, cur, n_cur);
+  const int V = ctx->hp.n_vocab;
   int best = 0;
-  float bv = NEG;
+  float bv = -INFINITY;
   for (int i = 0; i < V; ++i) if (logits[i] > bv) { bv = logits[i]; best = i; }
   if (logprob_out) *logprob_out = bv - lse;
   return best;
+}
+
+// whisper.cpp's decoders draw with std::mt19937 (seeded 0 once per whisper_full call) through
+// std::discrete_distribution over exp(logprobs): whisper_sample_token with best = false
+struct ohw_rng { std::mt19937 gen; };
+ohw_rng* ohw_rng_new(uint32_t seed) { return new (std::nothrow) ohw_rng{std::mt19937(seed)}; }
+void ohw_rng_free(ohw_rng* r) { delete r; }
+
+int32_t ohw_sample_host(const ohw_ctx* ctx, const ohw_sample_params* p, float* logits, const int32_t* cur, int n_cur, float temperature,
+                        ohw_rng* rng, float* logprob_out, float* no_speech_prob_out) {
+  if (!ctx || !p || !logits) return -1;
+  const int V = ctx->hp.n_vocab;
+  if (temperature > 0.0f) for (int i = 0; i < V; ++i) logits[i] /= temperature;
+  if (no_speech_prob_out && n_cur == 0) {
+    float mx = -INFINITY;
+    for (int i = 0; i < V; ++i) mx = std::max(mx, logits[i]);
+    double sum = 0.0;
+    for (int i = 0; i < V; ++i) sum += std::exp((double)(logits[i] - mx));
+    *no_speech_prob_out = (float)std::exp((double)(logits[ctx->tok.nosp] - mx) - std::log(sum));
+  }
+  if (!(temperature > 0.0f)) return ohw_sample_greedy_host(ctx, p, logits, cur, n_cur, logprob_out);
+  if (!rng) return -1;
+  const float lse = filter_logits(ctx, p, logits, cur, n_cur);
+  std::vector<float> probs((size_t)V);
+  for (int i = 0; i < V; ++i) probs[(size_t)i] = logits[i] > -INFINITY ? std::exp(logits[i] - lse) : 0.0f;
+  std::discrete_distribution<> dist(probs.begin(), probs.end());
+  const int id = dist(rng->gen);
+  if (logprob_out) *logprob_out = logits[id] - lse;
+  return id;
 }
 
 int ohw_detect_language(ohw_state* st, int batch, int32_t* lang_ids_out, float* lang_probs_out) {
@@ -273,73 +402,155 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
 
     e->last_tokens.clear();
     e->last_quality.clear();
+    e->last_trace.clear();
     std::string text;
     const int max_tok = e->ctx->hp.n_text_ctx;
-    // whisper.cpp's per-window acceptance test (as recalled): token-frequency entropy of the last 32 tokens
-    // and the average log-probability
-    auto quality = [&](const int32_t* t, int n, float sum_lp) {
-      ohw_window_quality q{};
-      q.n_tokens = n;
-      q.avg_logprob = n > 0 ? sum_lp / (float)n : 0.0f;
-      const int n32 = std::min(32, n);
-      double ent = 0.0;
-      for (int i = n - n32; i < n; ++i) {
-        bool first = true;
-        int cnt = 0;
-        for (int j = n - n32; j < n; ++j) {
-          if (t[j] == t[i]) { if (j < i) first = false; ++cnt; }
-        }
-        if (first && n32 > 0) { const double pr = (double)cnt / n32; ent -= pr * std::log(pr); }
-      }
-      q.entropy = (float)ent;
-      q.would_fallback = (n > 0 && (q.entropy < 2.4f || q.avg_logprob < -1.0f)) ? 1 : 0;
-      e->last_quality.push_back(q);
+    const int V = e->ctx->hp.n_vocab;
+    const int n_max = sp.n_max;
+    const ohw_decode_policy& pol = e->policy;
+    const std::vector<float> temps = ladder(pol);
+    int32_t prompt[8];
+    int n_prompt = 0;
+    prompt[n_prompt++] = tk.sot;
+    if (V >= 51865) { prompt[n_prompt++] = tk.sot + 1 + sp.lang_id; prompt[n_prompt++] = sp.translate ? tk.translate : tk.transcribe; }
+    if (sp.no_timestamps) prompt[n_prompt++] = tk.no_timestamps;
+    auto check = [&](int rc) { if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: " + g_last_error); };   // reference :266-268
+    auto trace = [&](int64_t window, float temp, const std::vector<int32_t>& t) {
+      e->last_trace.push_back((int32_t)window); e->last_trace.push_back((int32_t)std::lround(temp * 1000.f)); e->last_trace.push_back((int32_t)t.size());
+      e->last_trace.insert(e->last_trace.end(), t.begin(), t.end());
     };
-    auto append_text = [&](const int32_t* t, int n) {
-      for (int i = 0; i < n; ++i) {
-        e->last_tokens.push_back(t[i]);
-        if (t[i] < tk.eot) {                                                // segment text = text tokens only (:271-279)
+
+    // T = 0: the device-resident greedy loop for B windows; then whisper.cpp's bookkeeping per window
+    std::vector<int32_t> toks((size_t)e->max_batch * max_tok), ntok((size_t)e->max_batch), eot((size_t)e->max_batch);
+    std::vector<float> lps((size_t)e->max_batch * (max_tok + 1)), nsp((size_t)e->max_batch);
+    auto greedy_t0 = [&](ohw_state* st, int B, const int* seek, const int* seek_end, int64_t w0, std::vector<WindowRun>& runs) {
+      ohw_greedy_result gr{};
+      gr.tokens = toks.data(); gr.n_tokens = ntok.data(); gr.token_logprobs = lps.data(); gr.ended_by_eot = eot.data(); gr.no_speech_prob = nsp.data();
+      check(ohw_greedy_ex(st, &sp, B, max_tok, &gr));
+      runs.assign((size_t)B, WindowRun());
+      for (int b = 0; b < B; ++b) {
+        WindowRun& r = runs[(size_t)b];
+        const int nt = ntok[(size_t)b] + (eot[(size_t)b] ? 1 : 0);
+        r.tok.assign(&toks[(size_t)b * max_tok], &toks[(size_t)b * max_tok] + ntok[(size_t)b]);
+        if (eot[(size_t)b]) r.tok.push_back(tk.eot);
+        r.plog.assign(&lps[(size_t)b * (max_tok + 1)], &lps[(size_t)b * (max_tok + 1)] + nt);
+        r.nosp = nsp[(size_t)b];
+        r.ev = evaluate_sequence(tk, r.tok.data(), r.plog.data(), nt, seek[b], seek_end[b], n_max, sp.no_timestamps != 0, e->window_mode);
+        r.t0_failed = needs_fallback(r.ev, pol, r.nosp, false);
+        r.pending = needs_fallback(r.ev, pol, r.nosp, temps.empty());
+        trace(w0 + b, 0.f, r.tok);
+      }
+    };
+    // the temperature ladder for the windows of a batch whose pass failed the acceptance test: the HOST samples
+    // (std::mt19937 + std::discrete_distribution, as whisper.cpp's decoders do), the device runs the decoder steps of the
+    // pending windows only and re-uses their resident cross K/V; the logits of the pending rows cross PCIe every step
+    std::vector<float> logits;
+    auto run_ladder = [&](ohw_state* st, int B, const int* seek, const int* seek_end, int64_t w0, std::vector<WindowRun>& runs,
+                          const std::vector<ohw_rng*>& rngs) {
+      for (size_t ti = 0; ti < temps.size(); ++ti) {
+        std::vector<int32_t> active((size_t)B, 0);
+        bool any = false;
+        for (int b = 0; b < B; ++b) if (runs[(size_t)b].pending) { active[(size_t)b] = 1; any = true; }
+        if (!any) break;
+        const float T = temps[ti];
+        const bool is_last = ti + 1 == temps.size();
+        logits.resize((size_t)B * V);
+        std::vector<int32_t> ptoks((size_t)B * n_prompt), past((size_t)B, 0), feed((size_t)B, tk.eot), npast((size_t)B, n_prompt), live = active;
+        for (int b = 0; b < B; ++b) std::memcpy(&ptoks[(size_t)b * n_prompt], prompt, (size_t)n_prompt * 4);
+        check(ohw_decode_active(st, ptoks.data(), n_prompt, past.data(), B, active.data(), logits.data()));
+        std::vector<WindowRun> pass((size_t)B);
+        for (int i = 0; i < n_max; ++i) {
+          bool any_live = false;
+          for (int b = 0; b < B; ++b) {
+            if (!live[(size_t)b]) continue;
+            WindowRun& r = pass[(size_t)b];
+            float lp = 0.f;
+            const int32_t t = ohw_sample_host(e->ctx, &sp, &logits[(size_t)b * V], r.tok.data(), (int)r.tok.size(), T, rngs[(size_t)b], &lp, &r.nosp);
+            if (t < 0) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: host sampler");
+            r.tok.push_back(t); r.plog.push_back(lp);
+            const SeqEval ev = evaluate_sequence(tk, r.tok.data(), r.plog.data(), (int)r.tok.size(), seek[b], seek_end[b], n_max,
+                                                 sp.no_timestamps != 0, e->window_mode);
+            if (t == tk.eot || ev.completed || ev.failed || (int)r.tok.size() >= n_max || npast[(size_t)b] + 1 >= max_tok) live[(size_t)b] = 0;
+            else { feed[(size_t)b] = t; any_live = true; }
+          }
+          if (!any_live) break;
+          check(ohw_decode_active(st, feed.data(), 1, npast.data(), B, live.data(), logits.data()));
+          for (int b = 0; b < B; ++b) if (live[(size_t)b]) ++npast[(size_t)b];
+        }
+        for (int b = 0; b < B; ++b) {
+          if (!active[(size_t)b]) continue;
+          WindowRun& r = pass[(size_t)b];
+          r.temp = T;
+          r.ev = evaluate_sequence(tk, r.tok.data(), r.plog.data(), (int)r.tok.size(), seek[b], seek_end[b], n_max, sp.no_timestamps != 0, e->window_mode);
+          r.t0_failed = runs[(size_t)b].t0_failed;
+          r.pending = needs_fallback(r.ev, pol, r.nosp, is_last);
+          trace(w0 + b, T, r.tok);
+          runs[(size_t)b] = std::move(r);
+        }
+      }
+    };
+    auto emit = [&](const WindowRun& r) {
+      // whisper.cpp (>= 1.7.3 as recalled): a window whose no-speech probability is high AND whose text is unlikely is dropped
+      const bool no_speech = r.nosp > pol.no_speech_thold && r.ev.avg_logprob < pol.logprob_thold;
+      const int keep = no_speech ? 0 : r.ev.n_keep;
+      for (int i = 0; i < keep; ++i) {
+        e->last_tokens.push_back(r.tok[(size_t)i]);
+        if (r.tok[(size_t)i] < tk.eot) {                                    // segment text = text tokens only (:271-279)
           const char* sp_ = nullptr;
-          const int len = ohw_token_text(e->ctx, t[i], &sp_);
+          const int len = ohw_token_text(e->ctx, r.tok[(size_t)i], &sp_);
           text.append(sp_, (size_t)len);
         }
       }
+      ohw_window_quality q{};
+      q.n_tokens = keep; q.avg_logprob = r.ev.avg_logprob; q.entropy = r.ev.entropy; q.would_fallback = r.t0_failed ? 1 : 0;
+      q.temperature = r.temp; q.no_speech_prob = r.nosp; q.no_speech = no_speech ? 1 : 0; q.seek_delta = r.ev.seek_delta;
+      q.result_len = r.ev.result_len; q.failed = r.ev.failed ? 1 : 0;
+      e->last_quality.push_back(q);
     };
+    struct Rngs {   // whisper.cpp seeds every decoder's generator with 0 once per whisper_full call
+      std::vector<ohw_rng*> v;
+      ~Rngs() { for (ohw_rng* r : v) ohw_rng_free(r); }
+      void reset(size_t nr) { for (ohw_rng* r : v) ohw_rng_free(r); v.clear(); for (size_t i = 0; i < nr; ++i) v.push_back(ohw_rng_new(0)); }
+    } rngs;
+
     if (e->window_mode == OHW_WINDOW_SEEK) {
-      // whisper.cpp's seek loop as recalled: sequential windows, advanced by the last timestamp
-      std::vector<int32_t> toks((size_t)max_tok);
-      int32_t ntok = 0;
-      float slp = 0.f;
-      const int64_t seek_end = n / HOP;               // 10 ms frames
-      int64_t seek = 0;
-      while (seek + 100 < seek_end) {
-        const int64_t off = seek * HOP;
+      // whisper.cpp's seek loop as recalled: sequential windows, advanced by the last timestamp; one
+      // generator for the whole call
+      rngs.reset(1);
+      const int seek_end = mel_frames(n);
+      int seek = 0;
+      std::vector<WindowRun> runs;
+      int64_t w = 0;
+      while (seek_end >= 100 && seek + 100 < seek_end) {
+        const int64_t off = (int64_t)seek * HOP;
         const int32_t ns1 = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - off);
-        int rc = ohw_mel(e->state, samples + off, CHUNK_SAMPLES, &ns1, 1, 0, OHW_MEL_ZERO_TAIL, nullptr);
-        if (rc == OHW_OK) rc = ohw_encode(e->state, 1);
-        if (rc == OHW_OK) rc = ohw_greedy(e->state, &sp, 1, toks.data(), &ntok, max_tok, &slp);
-        if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: " + g_last_error);
-        int64_t seek_delta = 100 * 30;                // a full window when no timestamp was produced
-        int result_len = ntok;
-        for (int i = 0; i < ntok; ++i)
-          if (toks[(size_t)i] > tk.timestamp_begin) { seek_delta = 2 * (int64_t)(toks[(size_t)i] - tk.timestamp_begin); result_len = i + 1; }
-        if (seek_delta <= 0) seek_delta = 100 * 30;
-        quality(toks.data(), ntok, slp);
-        append_text(toks.data(), result_len);
-        seek += seek_delta;
+        check(ohw_mel(e->state, samples + off, CHUNK_SAMPLES, &ns1, 1, 0, OHW_MEL_ZERO_TAIL, nullptr));
+        check(ohw_encode(e->state, 1));
+        greedy_t0(e->state, 1, &seek, &seek_end, w, runs);
+        run_ladder(e->state, 1, &seek, &seek_end, w, runs, rngs.v);
+        emit(runs[0]);
+        seek += runs[0].ev.seek_delta > 0 ? runs[0].ev.seek_delta : 3000;
+        ++w;
       }
     } else {
-      // host-side windowing: fixed 30 s cuts (BASELINE.json north_star)
+      // host-side windowing: fixed 30 s cuts (BASELINE.json north_star).  Each cut is its own `full` call in
+      // whisper.cpp terms: seek 0, its own frame count as the end of the audio, a fresh generator - and, like a call with
+      // less than 1 s of audio (`seek + 100 >= seek_end` before the first window), a cut of at most 100 frames yields nothing
       const int64_t n_win = (n + CHUNK_SAMPLES - 1) / CHUNK_SAMPLES;
-      std::vector<int32_t> toks((size_t)e->max_batch * max_tok), ntok((size_t)e->max_batch), ns((size_t)e->max_batch);
-      std::vector<float> slp((size_t)e->max_batch);
+      std::vector<int32_t> ns((size_t)e->max_batch);
       const int64_t n_batches = (n_win + e->max_batch - 1) / e->max_batch;
       auto batch_of = [&](int64_t bi) { return (int)std::min<int64_t>(e->max_batch, n_win - bi * e->max_batch); };
-      auto collect = [&](int B) {
-        for (int b = 0; b < B; ++b) {
-          quality(&toks[(size_t)b * max_tok], ntok[(size_t)b], slp[(size_t)b]);
-          append_text(&toks[(size_t)b * max_tok], ntok[(size_t)b]);
-        }
+      std::vector<int> zero((size_t)e->max_batch, 0), ends((size_t)e->max_batch);
+      std::vector<WindowRun> runs;
+      auto decode_batch = [&](ohw_state* st, int64_t bi, const int32_t* nsb) {
+        const int B = batch_of(bi);
+        for (int b = 0; b < B; ++b) ends[(size_t)b] = mel_frames(nsb[b]);
+        greedy_t0(st, B, zero.data(), ends.data(), bi * e->max_batch, runs);
+        for (int b = 0; b < B; ++b) if (ends[(size_t)b] <= 100) { runs[(size_t)b] = WindowRun(); runs[(size_t)b].ev.result_len = 0; }
+        bool any = false;
+        for (int b = 0; b < B; ++b) any = any || runs[(size_t)b].pending;
+        if (any) { rngs.reset((size_t)B); run_ladder(st, B, zero.data(), ends.data(), bi * e->max_batch, runs, rngs.v); }
+        for (int b = 0; b < B; ++b) emit(runs[(size_t)b]);
       };
       bool pipelined = n_batches > 1 && e->enc_cus > 0;
       if (pipelined && !e->state2) {
@@ -364,18 +575,15 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
           const int64_t w0 = bi * e->max_batch;
           const int B = batch_of(bi);
           for (int b = 0; b < B; ++b) ns[(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + b) * CHUNK_SAMPLES);
-          int rc = ohw_mel(e->state, samples + w0 * CHUNK_SAMPLES, CHUNK_SAMPLES, ns.data(), B, 0, OHW_MEL_ZERO_TAIL, nullptr);
-          if (rc == OHW_OK) rc = ohw_encode(e->state, B);
-          if (rc == OHW_OK) rc = ohw_greedy(e->state, &sp, B, toks.data(), ntok.data(), max_tok, slp.data());
-          if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: " + g_last_error);   // reference :266-268
-          collect(B);
+          check(ohw_mel(e->state, samples + w0 * CHUNK_SAMPLES, CHUNK_SAMPLES, ns.data(), B, 0, OHW_MEL_ZERO_TAIL, nullptr));
+          check(ohw_encode(e->state, B));
+          decode_batch(e->state, bi, ns.data());
         }
       } else {
         // mel + encoder + cross-K/V of batch i+1 (MFMA-bound) run beside the greedy decode of batch i (HBM- and
         // latency-bound) on disjoint CUs; the first front end and the last decode have the device to themselves
         ohw_state* sts[2] = {e->state, e->state2};
         std::vector<int32_t> ns2[2] = {std::vector<int32_t>((size_t)e->max_batch), std::vector<int32_t>((size_t)e->max_batch)};
-        auto check = [&](int rc) { if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: " + g_last_error); };
         auto restore = [&] { (void)ohw_state_set_stream(e->state, nullptr); (void)ohw_state_set_stream(e->state2, nullptr); };
         auto front = [&](int64_t bi, void* stream) {
           ohw_state* st = sts[bi & 1];
@@ -400,9 +608,7 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
               last_front = e->s_enc;
             }
             check(ohw_state_set_stream(sts[bi & 1], dstream));
-            const int B = batch_of(bi);
-            check(ohw_greedy(sts[bi & 1], &sp, B, toks.data(), ntok.data(), max_tok, slp.data()));
-            collect(B);
+            decode_batch(sts[bi & 1], bi, ns2[bi & 1].data());
           }
         } catch (...) {
           (void)hipDeviceSynchronize();
@@ -431,6 +637,24 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
     if (duration_ms)
       *duration_ms = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
   });
+}
+
+void ohw_default_decode_policy(ohw_decode_policy* q) {
+  if (!q) return;
+  q->temperature_inc = 0.2f; q->entropy_thold = 2.4f; q->logprob_thold = -1.0f; q->no_speech_thold = 0.6f;
+}
+
+int ohw_engine_set_decode_policy(ohw_engine* e, const ohw_decode_policy* q) {
+  if (!e || !q) return OHW_E_INVALID_ARG;
+  e->policy = *q;
+  return OHW_OK;
+}
+
+int ohw_engine_last_trace(ohw_engine* e, const int32_t** data, int* n) {
+  if (!e || !data || !n) return OHW_E_INVALID_ARG;
+  *data = e->last_trace.data();
+  *n = (int)e->last_trace.size();
+  return OHW_OK;
 }
 
 int ohw_engine_last_text(ohw_engine* e, const char** text, size_t* len) {

@@ -70,7 +70,14 @@ class GreedyResult(C.Structure):
 
 
 class WindowQuality(C.Structure):
-    _fields_ = [("n_tokens", C.c_int32), ("avg_logprob", C.c_float), ("entropy", C.c_float), ("would_fallback", C.c_int32)]
+    _fields_ = [("n_tokens", C.c_int32), ("avg_logprob", C.c_float), ("entropy", C.c_float), ("would_fallback", C.c_int32),
+                ("temperature", C.c_float), ("no_speech_prob", C.c_float), ("no_speech", C.c_int32), ("seek_delta", C.c_int32),
+                ("result_len", C.c_int32), ("failed", C.c_int32)]
+
+
+class DecodePolicy(C.Structure):
+    """ohw_decode_policy: whisper.cpp's defaults (temperature_inc 0.2, entropy_thold 2.4, logprob_thold -1.0, no_speech_thold 0.6)"""
+    _fields_ = [("temperature_inc", C.c_float), ("entropy_thold", C.c_float), ("logprob_thold", C.c_float), ("no_speech_thold", C.c_float)]
 
 
 class Timings(C.Structure):
@@ -92,6 +99,8 @@ EXPORTS = [
     "ohw_default_preprocess_config", "ohw_preprocess_audio", "ohw_dsp_rms_db", "ohw_dsp_apply_gain", "ohw_dsp_normalize_rms",
     "ohw_dsp_compress", "ohw_dsp_limit", "ohw_dsp_resample_linear",
     "ohw_greedy_ex", "ohw_state_set_logit_bias", "ohw_dbg_sample",
+    "ohw_decode_active", "ohw_rng_new", "ohw_rng_free", "ohw_sample_host", "ohw_default_decode_policy", "ohw_engine_set_decode_policy",
+    "ohw_engine_last_trace",
 ]
 
 
@@ -184,6 +193,16 @@ def lib():
         L.ohw_greedy_ex.argtypes = [vp, C.POINTER(SampleParams), C.c_int, C.c_int, C.POINTER(GreedyResult)]
         L.ohw_state_set_logit_bias.argtypes = [vp, fp, C.c_int]
         L.ohw_dbg_sample.argtypes = [vp, C.POINTER(SampleParams), fp, ip, C.c_int, ip, C.c_int, ip, fp, fp]
+        L.ohw_decode_active.argtypes = [vp, ip, C.c_int, ip, C.c_int, ip, fp]
+        L.ohw_rng_new.argtypes = [C.c_uint32]
+        L.ohw_rng_new.restype = vp
+        L.ohw_rng_free.argtypes = [vp]
+        L.ohw_rng_free.restype = None
+        L.ohw_sample_host.argtypes = [vp, C.POINTER(SampleParams), fp, ip, C.c_int, C.c_float, vp, fp, fp]
+        L.ohw_default_decode_policy.argtypes = [C.POINTER(DecodePolicy)]
+        L.ohw_default_decode_policy.restype = None
+        L.ohw_engine_set_decode_policy.argtypes = [vp, C.POINTER(DecodePolicy)]
+        L.ohw_engine_last_trace.argtypes = [vp, C.POINTER(ip), C.POINTER(C.c_int)]
         L.ohw_state_timings.argtypes = [vp, C.POINTER(Timings)]
         L.ohw_engine_new.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.ohw_engine_transcribe.argtypes = [vp, fp, C.c_int64, C.c_uint32, C.c_char_p, C.c_size_t, C.c_char_p,
@@ -324,6 +343,14 @@ class Context:
         tok = lib().ohw_sample_greedy_host(self.h, C.byref(p), _fp(lg), _ip(c), len(cur), C.byref(lp))
         return int(tok), float(lp.value)
 
+    def sample_host(self, p: SampleParams, logits: np.ndarray, cur: List[int], temperature: float, rng: Optional["HostRng"]):
+        """ohw_sample_host -> (token, logprob, no_speech_prob or None)"""
+        lg = np.ascontiguousarray(logits, dtype=np.float32).copy()
+        c = np.asarray(cur if len(cur) else [0], dtype=np.int32)
+        lp, ns = C.c_float(0), C.c_float(-1)
+        tok = lib().ohw_sample_host(self.h, C.byref(p), _fp(lg), _ip(c), len(cur), temperature, rng.h if rng else None, C.byref(lp), C.byref(ns))
+        return int(tok), float(lp.value), (float(ns.value) if len(cur) == 0 else None)
+
     def close(self):
         if getattr(self, "h", None):
             lib().ohw_ctx_free(self.h)
@@ -332,6 +359,20 @@ class Context:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+class HostRng:
+    """ohw_rng: the std::mt19937 whisper.cpp's decoders sample with (seed 0 per call)"""
+    def __init__(self, seed: int = 0):
+        self.h = C.c_void_p(lib().ohw_rng_new(seed))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().ohw_rng_free(self.h)
+                self.h = None
         except Exception:
             pass
 
@@ -420,6 +461,16 @@ class State:
         npast = np.asarray(n_past, dtype=np.int32)
         out = np.empty((B, self.ctx.hp.n_vocab), dtype=np.float32)
         _check(lib().ohw_decode(self.h, _ip(t), n_new, _ip(npast), B, _fp(out)))
+        return out
+
+    def decode_active(self, tokens: np.ndarray, n_past: Sequence[int], active: Sequence[int]) -> np.ndarray:
+        """ohw_decode_active: as decode(), only the windows with active[b] != 0 (the other rows of the result are zero)"""
+        t = np.ascontiguousarray(np.atleast_2d(tokens), dtype=np.int32)
+        B, n_new = t.shape
+        npast = np.asarray(n_past, dtype=np.int32)
+        act = np.asarray(active, dtype=np.int32)
+        out = np.zeros((B, self.ctx.hp.n_vocab), dtype=np.float32)
+        _check(lib().ohw_decode_active(self.h, _ip(t), n_new, _ip(npast), B, _ip(act), _fp(out)))
         return out
 
     def greedy(self, batch: int, p: Optional[SampleParams] = None):
@@ -644,10 +695,42 @@ class WhisperEngine:
 
     def last_quality(self):
         """[(n_tokens, avg_logprob, entropy, would_fallback)] per window of the last transcribe"""
+        return [(q["n_tokens"], q["avg_logprob"], q["entropy"], q["would_fallback"]) for q in self.last_quality_ex()]
+
+    def last_quality_ex(self):
+        """one dict per window of the last transcribe with every ohw_window_quality field"""
         q = C.POINTER(WindowQuality)()
         n = C.c_int(0)
         _check(lib().ohw_engine_last_quality(self.h, C.byref(q), C.byref(n)))
-        return [(q[i].n_tokens, q[i].avg_logprob, q[i].entropy, bool(q[i].would_fallback)) for i in range(n.value)]
+        out = []
+        for i in range(n.value):
+            d = {name: getattr(q[i], name) for name, _ in WindowQuality._fields_}
+            d["would_fallback"], d["no_speech"], d["failed"] = bool(d["would_fallback"]), bool(d["no_speech"]), bool(d["failed"])
+            out.append(d)
+        return out
+
+    def set_decode_policy(self, temperature_inc: Optional[float] = None, entropy_thold: Optional[float] = None,
+                          logprob_thold: Optional[float] = None, no_speech_thold: Optional[float] = None):
+        """ohw_engine_set_decode_policy: whisper.cpp's defaults unless overridden; temperature_inc = 0 keeps every window at T = 0"""
+        pol = DecodePolicy()
+        lib().ohw_default_decode_policy(C.byref(pol))
+        for k, v in (("temperature_inc", temperature_inc), ("entropy_thold", entropy_thold), ("logprob_thold", logprob_thold),
+                     ("no_speech_thold", no_speech_thold)):
+            if v is not None:
+                setattr(pol, k, v)
+        _check(lib().ohw_engine_set_decode_policy(self.h, C.byref(pol)))
+
+    def last_trace(self):
+        """[(window, temperature, [sampled tokens, end-of-text included])] for every decode pass of the last transcribe"""
+        p = C.POINTER(C.c_int32)()
+        n = C.c_int(0)
+        _check(lib().ohw_engine_last_trace(self.h, C.byref(p), C.byref(n)))
+        out, i = [], 0
+        while i + 3 <= n.value:
+            w, t, k = p[i], p[i + 1], p[i + 2]
+            out.append((int(w), t / 1000.0, [int(p[i + 3 + j]) for j in range(k)]))
+            i += 3 + k
+        return out
 
     def set_window_mode(self, mode: int):
         """OHW_WINDOW_FIXED (0, default) or OHW_WINDOW_SEEK (1, whisper.cpp's timestamp-driven loop)"""

@@ -37,6 +37,34 @@ class SampleParams(C.Structure):
                 ("force_len", C.c_int32)]
 
 
+class DecodePolicy(C.Structure):
+    _fields_ = [("temperature_inc", C.c_float), ("entropy_thold", C.c_float), ("logprob_thold", C.c_float), ("no_speech_thold", C.c_float)]
+
+
+class SeqEval(C.Structure):
+    _fields_ = [("n_sampled", C.c_int32), ("result_len", C.c_int32), ("n_keep", C.c_int32), ("seek_delta", C.c_int32),
+                ("failed", C.c_int32), ("completed", C.c_int32), ("avg_logprob", C.c_float), ("entropy", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class WindowResult(C.Structure):
+    _fields_ = [("ev", SeqEval), ("temperature", C.c_float), ("no_speech_prob", C.c_float), ("n_passes", C.c_int32), ("no_speech", C.c_int32)]
+
+
+class MT19937(C.Structure):
+    """oracle's own Mersenne twister (std::mt19937 semantics)"""
+    _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int)]
+
+    def __init__(self, seed: int = 0):
+        super().__init__()
+        lib().ref_mt_seed(C.byref(self), seed)
+
+    def next(self) -> int:
+        return int(lib().ref_mt_next(C.byref(self)))
+
+
 AUDIO_ERRORS = {0: "Ok", 1: "Empty", 2: "InvalidSampleRate", 3: "TooLong", 4: "TooShort", 5: "ContainsNaN", 6: "ContainsInfinite"}
 
 _lib = None
@@ -85,6 +113,18 @@ def lib():
         L.ref_greedy_ex.argtypes = [C.c_void_p, C.POINTER(SampleParams), fp, ip, C.c_int, ip, fp, fp, ip, ip, fp]
         L.ref_transcribe_chunk.argtypes = [C.c_void_p, fp, C.c_int64, C.c_int, C.POINTER(SampleParams), ip,
                                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        dp = C.POINTER(C.c_double)
+        L.ref_default_decode_policy.argtypes = [C.POINTER(DecodePolicy)]
+        L.ref_mel_frames.argtypes = [C.c_int64]
+        L.ref_mt_seed.argtypes = [C.POINTER(MT19937), C.c_uint32]
+        L.ref_mt_next.argtypes = [C.POINTER(MT19937)]
+        L.ref_mt_next.restype = C.c_uint32
+        L.ref_evaluate_sequence.argtypes = [C.c_void_p, ip, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SeqEval)]
+        L.ref_pass_needs_fallback.argtypes = [C.POINTER(SeqEval), C.POINTER(DecodePolicy), C.c_float, C.c_int]
+        L.ref_window_is_no_speech.argtypes = [C.POINTER(SeqEval), C.POINTER(DecodePolicy), C.c_float]
+        L.ref_decode_pass.argtypes = [C.c_void_p, C.POINTER(SampleParams), fp, C.c_float, C.POINTER(MT19937), ip, C.c_int, ip, fp, ip, fp, dp, fp]
+        L.ref_decode_window.argtypes = [C.c_void_p, C.POINTER(SampleParams), C.POINTER(DecodePolicy), fp, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(MT19937), ip, fp, C.POINTER(WindowResult)]
         L.ref_num_threads.restype = C.c_int
         L.ref_set_num_threads.argtypes = [C.c_int]
         _lib = L
@@ -296,6 +336,68 @@ def _state_greedy_ex(self, p: Optional[SampleParams] = None, bias: Optional[np.n
 
 
 State.greedy_ex = _state_greedy_ex
+
+
+def default_policy() -> DecodePolicy:
+    q = DecodePolicy()
+    lib().ref_default_decode_policy(C.byref(q))
+    return q
+
+
+def mel_frames(n_samples: int) -> int:
+    return int(lib().ref_mel_frames(n_samples))
+
+
+def evaluate_sequence(model: Model, tokens, plogs, seek: int, seek_end: int, n_max: int, no_timestamps: bool = False, window_mode: int = 0) -> SeqEval:
+    t = np.asarray(list(tokens) or [0], dtype=np.int32)
+    l = np.asarray(list(plogs) or [0.0], dtype=np.float32)
+    ev = SeqEval()
+    lib().ref_evaluate_sequence(model.h, _ip(t), _fp(l), len(tokens), seek, seek_end, n_max, int(no_timestamps), window_mode, C.byref(ev))
+    return ev
+
+
+def pass_needs_fallback(ev: SeqEval, pol: DecodePolicy, no_speech_prob: float, is_last: bool) -> bool:
+    return bool(lib().ref_pass_needs_fallback(C.byref(ev), C.byref(pol), no_speech_prob, int(is_last)))
+
+
+def window_is_no_speech(ev: SeqEval, pol: DecodePolicy, no_speech_prob: float) -> bool:
+    return bool(lib().ref_window_is_no_speech(C.byref(ev), C.byref(pol), no_speech_prob))
+
+
+def _state_decode_pass(self, p: SampleParams, bias, temperature: float, rng: Optional[MT19937], forced=None):
+    """One pass over the window at `temperature`: dict(tokens (end-of-text last when sampled), plogs, choice, margins, gaps,
+    no_speech_prob).  With `forced` the walk follows those tokens; choice / margins (T = 0) / gaps (T > 0: distance of the
+    draw to the nearer edge of the chosen interval) record what the oracle itself would have done at every step."""
+    cap = self.m.n_text_ctx + 1
+    out = np.zeros(cap, np.int32); lps = np.zeros(cap, np.float32); ch = np.full(cap, -1, np.int32)
+    mg = np.zeros(cap, np.float32); gaps = np.ones(cap, np.float64)
+    ns = C.c_float(0)
+    nul = C.cast(None, C.POINTER(C.c_float))
+    bp = _fp(np.ascontiguousarray(bias, dtype=np.float32)) if bias is not None else nul
+    f = np.asarray(forced, dtype=np.int32) if forced is not None and len(forced) else None
+    n = lib().ref_decode_pass(self.h, C.byref(p), bp, temperature, C.byref(rng) if rng is not None else None,
+                              _ip(f) if f is not None else C.cast(None, C.POINTER(C.c_int32)), len(f) if f is not None else 0,
+                              _ip(out), _fp(lps), _ip(ch), _fp(mg), gaps.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ns))
+    steps = int((ch >= 0).sum())
+    return {"tokens": [int(x) for x in out[:n]], "plogs": lps[:n].copy(), "choice": [int(x) for x in ch[:steps]],
+            "margins": mg[:steps].copy(), "gaps": gaps[:steps].copy(), "no_speech_prob": float(ns.value)}
+
+
+def _state_decode_window(self, p: SampleParams, pol: DecodePolicy, bias=None, seek: int = 0, seek_end: int = 2999, window_mode: int = 0,
+                         rng: Optional[MT19937] = None):
+    """whisper.cpp's whole per-window procedure (T = 0, then the ladder): (kept tokens, WindowResult, all sampled tokens)"""
+    cap = self.m.n_text_ctx + 1
+    out = np.zeros(cap, np.int32); lps = np.zeros(cap, np.float32)
+    res = WindowResult()
+    nul = C.cast(None, C.POINTER(C.c_float))
+    bp = _fp(np.ascontiguousarray(bias, dtype=np.float32)) if bias is not None else nul
+    n = lib().ref_decode_window(self.h, C.byref(p), C.byref(pol), bp, seek, seek_end, window_mode, C.byref(rng) if rng is not None else None,
+                                _ip(out), _fp(lps), C.byref(res))
+    return [int(x) for x in out[:n]], res, [int(x) for x in out[:res.ev.n_sampled]]
+
+
+State.decode_pass = _state_decode_pass
+State.decode_window = _state_decode_window
 
 
 def num_threads() -> int:

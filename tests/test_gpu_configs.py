@@ -107,6 +107,7 @@ def test_engine_built_on_one_thread_used_and_freed_on_another(E, tmp_models):
 
     def builder():
         box["eng"] = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_F16, 2)
+        box["eng"].set_decode_policy(temperature_inc=0.0)       # T = 0 only (the ladder: test_gpu_policy.py)
         box["first"] = box["eng"].transcribe(E.AudioBuffer(pcm, 16000)).text      # also used once where it was built
 
     def worker():
@@ -119,6 +120,7 @@ def test_engine_built_on_one_thread_used_and_freed_on_another(E, tmp_models):
             eng.close()                                                             # dropped on the worker thread
             # lazy re-load after an idle unload (reference src/daemon.rs:2242-2283): a new engine on this thread
             e2 = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_F16, 2)
+            e2.set_decode_policy(temperature_inc=0.0)
             box["third"] = e2.transcribe(E.AudioBuffer(pcm, 16000)).text
             e2.close()
         except Exception as ex:       # surfaced in the main thread below
@@ -133,6 +135,7 @@ def test_engine_built_on_one_thread_used_and_freed_on_another(E, tmp_models):
 
     def both(i):
         e = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_F16, 1)
+        e.set_decode_policy(temperature_inc=0.0)
         outs[i] = e.transcribe(E.AudioBuffer(pcm, 16000)).text
         e.close()
 
@@ -166,8 +169,7 @@ def test_config4_one_hour_120_windows_on_one_gpu(E, large_v3_file, monkeypatch):
     for cus in ("96", "0"):
         monkeypatch.setenv("OHW_ENGINE_ENC_CUS", cus)
         eng = E.WhisperEngine.new(large_v3_file, "auto", False, True, 0, E.OHW_DTYPE_BF16, 32)
-        if hasattr(eng, "set_decode_policy"):
-            eng.set_decode_policy(temperature_inc=0.0)       # T = 0 only: the fallback ladder is a per-window host path
+        eng.set_decode_policy(temperature_inc=0.0)           # T = 0 only: the fallback ladder is a per-window host path
         res = eng.transcribe(E.AudioBuffer(pcm, 16000))
         q = eng.last_quality()
         out[cus] = (res.text, eng.last_tokens(), [x[0] for x in q])

@@ -134,6 +134,10 @@ def test_teacher_forced_logits(E, oracle, models, dt):
 
 @pytest.mark.parametrize("dt", [0, 1])
 def test_greedy_tokens_match_oracle(E, oracle, models, dt):
+    """Every step of the device greedy loop and of the host-sampler loop is compared: the oracle walks the GPU's own
+    token path (ref_greedy_ex with forced tokens) and must pick the same token at each step; a differing pick is
+    legitimate only where the oracle's own top-2 margin is inside twice the logit tolerance.  The compared / total
+    step counts are printed."""
     _, _, om, ctxs = models
     pcm, ns = _pcm_batch()
     st = E.State(ctxs[dt], 3)
@@ -141,26 +145,32 @@ def test_greedy_tokens_match_oracle(E, oracle, models, dt):
     st.encode(3)
     p = ctxs[dt].default_params()
     p.n_max = 40
-    dev_tokens, slp = st.greedy(3, p)
+    dev = st.greedy_ex(3, p)
     host_tokens = st.greedy_host_sampler(3, p)
     op = om.default_params()
     op.n_max = 40
     tol = TOL_LOGIT[dt]
+    same = total = 0
     for b in range(3):
         s = oracle.State(om)
         s.set_encoder_output(om.encode(mel[b]))
-        ref, lps, margins, _ = s.greedy(op)
-        for name, got in (("device", dev_tokens[b]), ("host", host_tokens[b])):
-            n = min(len(ref), len(got))
-            div = next((i for i in range(n) if ref[i] != got[i]), None)
-            if div is None:
-                assert len(ref) == len(got) or margins[n] < 2 * tol, (name, b, len(ref), len(got))
+        assert dev[b]["tokens"] == host_tokens[b], b
+        forced = dev[b]["tokens"] + ([om.tok_eot] if dev[b]["ended_by_eot"] else [])
+        ref = s.greedy_ex(op, None, forced)
+        assert len(ref["choice"]) >= len(forced)
+        lp_ok = True
+        for i, t in enumerate(forced):
+            total += 1
+            if ref["choice"][i] == t:
+                same += 1
+                lp_ok = lp_ok and abs(float(dev[b]["logprobs"][i]) - float(ref["logprobs"][i])) < 2 * tol
             else:
-                # a divergence is legitimate only at a near-tie of the oracle itself
-                assert margins[div] < 2 * tol, (name, b, div, margins[div], ref[:div + 1], got[:div + 1])
-        assert dev_tokens[b] == host_tokens[b], b
-        if dev_tokens[b] == ref:
-            assert abs(slp[b] - float(lps.sum())) < 0.05 * max(1, len(ref))
+                assert ref["margins"][i] < 2 * tol, (b, i, t, ref["choice"][i], float(ref["margins"][i]))
+        assert lp_ok, b
+        assert dev[b]["ended_by_eot"] or len(dev[b]["tokens"]) == 40
+        assert abs(dev[b]["sum_logprob"] - float(dev[b]["logprobs"][:len(dev[b]["tokens"])].sum())) < 1e-3 * max(1, len(forced))
+    print(f"greedy steps where the oracle picks the GPU's token: {same} / {total} (dtype {dt})")
+    assert same >= 0.9 * total
 
 
 def test_force_len_and_batch_invariance(E, models):
@@ -227,6 +237,7 @@ def test_synthetic_context_equals_file_context(E, models):
 def test_whisper_engine_mirror(E, oracle, models):
     preset, path, om, _ = models
     eng = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_F16, 2)
+    eng.set_decode_policy(temperature_inc=0.0)       # T = 0 only here; the temperature ladder has its own tests (test_gpu_policy.py)
     # 70 s -> three host-side 30 s windows (2 + 1 batches)
     pcm = np.concatenate([synth.synth_audio(21), synth.synth_audio(22), synth.synth_audio(23, 160000)])
     res = eng.transcribe(E.AudioBuffer(pcm, 16000))
@@ -243,17 +254,14 @@ def test_whisper_engine_mirror(E, oracle, models):
         assert agree >= 0.9 * n, (agree, n)
     text = b"".join(E.Context.token_text(_Ctx(eng), t) for t in toks if t < 50257)
     assert res.text == text.decode().strip()
-    # whisper.cpp's fallback criteria are reported per window (the engine itself stays greedy)
-    q = eng.last_quality()
-    assert len(q) == 3 and sum(n for n, *_ in q) == len(toks)
-    pos = 0
-    for n, avg_lp, ent, fb in q:
-        w = toks[pos:pos + n]; pos += n
-        last = w[-32:]
-        cnt = {t: last.count(t) for t in set(last)}
-        want = -sum(c / len(last) * np.log(c / len(last)) for c in cnt.values())
-        assert abs(ent - want) < 1e-4 and avg_lp <= 0.0
-        assert fb == (ent < 2.4 or avg_lp < -1.0)
+    # whisper.cpp's acceptance test is reported per window: procedural weights repeat one token and emit no timestamp,
+    # so every window ends in the repetition guard (failed, result_len 0) and, with the ladder off, is kept as decoded
+    q = eng.last_quality_ex()
+    assert len(q) == 3 and sum(x["n_tokens"] for x in q) == len(toks)
+    for x in q:
+        assert x["would_fallback"] and x["temperature"] == 0.0 and not x["no_speech"] and x["seek_delta"] == 3000
+        if x["failed"]:
+            assert x["result_len"] == 0 and x["n_tokens"] == 220
     # validation errors surface as ValidationFailed with the reference's variant
     with pytest.raises(E.ValidationFailed) as ei:
         eng.transcribe(E.AudioBuffer(np.zeros(800, np.float32), 16000))
@@ -289,6 +297,7 @@ def test_long_audio_two_batches_in_flight_equals_sequential(E, models, monkeypat
     for cus in ("0", "96", "200"):
         monkeypatch.setenv("OHW_ENGINE_ENC_CUS", cus)          # read when the engine is created; 0 = strictly sequential
         eng = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_BF16, 2)
+        eng.set_decode_policy(temperature_inc=0.0)
         r1 = eng.transcribe(E.AudioBuffer(pcm, 16000))
         t1 = eng.last_tokens()
         r2 = eng.transcribe(E.AudioBuffer(pcm[:480000 * 3 + 1000], 16000))     # the states and streams are reused
@@ -382,6 +391,7 @@ def test_large_v3_dims_one_window_matches_oracle(E, oracle):
     enc = st.fetch("enc", 1)[0]
     # 32 layers of bf16 GEMM operands: compare relative to the activation scale (LayerNorm output, O(1))
     err = np.abs(enc - ref_enc)
+    print(f"large-v3 encoder output vs oracle: max abs err {err.max():.4f}, mean {err.mean():.5f}")
     assert err.max() < 0.25 and err.mean() < 0.02, (err.max(), err.mean())
     s = oracle.State(om)
     s.set_encoder_output(ref_enc)
@@ -389,15 +399,18 @@ def test_large_v3_dims_one_window_matches_oracle(E, oracle):
     ref = s.decode(prompt, 0)
     got = st.decode(np.asarray([prompt], np.int32), [0])[0]
     sig = float(ref.std())
-    assert np.abs(got - ref).max() < 0.12 * sig, (np.abs(got - ref).max(), sig)
+    worst = float(np.abs(got - ref).max())
+    assert worst < 0.12 * sig, (worst, sig)
     tok = int(ref.argmax())
     margin = float(np.sort(ref)[-1] - np.sort(ref)[-2])
     assert int(got.argmax()) == tok or margin < 0.12 * sig
     for i in range(3):
         ref = s.decode([tok], 3 + i)
         got = st.decode(np.asarray([[tok]], np.int32), [3 + i])[0]
+        worst = max(worst, float(np.abs(got - ref).max()))
         assert np.abs(got - ref).max() < 0.12 * sig
         tok = int(ref.argmax())
+    print(f"large-v3 logits vs oracle: worst abs err {worst:.4f} at sigma {sig:.3f} ({worst / sig:.4f} sigma)")
     om.close()
 
 
@@ -512,41 +525,3 @@ def test_language_detection_matches_oracle(E, oracle, models):
         top2 = np.sort(lg)[-2:]
         assert ids[b] == int(lg.argmax()) or top2[1] - top2[0] < 2 * TOL_LOGIT[1]
     assert E.lang_id_to_code(int(ids[0])) != ""
-
-
-def test_seek_window_mode_matches_restated_loop(E, oracle, models):
-    """OHW_WINDOW_SEEK: whisper.cpp's timestamp-driven window loop (unpinned), restated here in
-    Python around the oracle: seek += 2 * (last timestamp - ts_begin), tokens after it dropped, stop below 1 s."""
-    preset, path, om, _ = models
-    eng = E.WhisperEngine.new(path, "en", False, True, 0, E.OHW_DTYPE_F16, 1)
-    eng.set_window_mode(E.OHW_WINDOW_SEEK)
-    pcm = np.concatenate([synth.synth_audio(41), synth.synth_audio(42, 200000)])
-    res = eng.transcribe(E.AudioBuffer(pcm, 16000))
-    got = eng.last_tokens()
-    ref, seek, seek_end, first_margin_problem = [], 0, len(pcm) // 160, None
-    op = om.default_params()
-    n_windows = 0
-    while seek + 100 < seek_end:
-        win = pcm[seek * 160: seek * 160 + 480000]
-        s = oracle.State(om)
-        s.set_encoder_output(om.encode(om.log_mel(win, 1)))
-        toks, _, margins, _ = s.greedy(op)
-        delta, rlen = 3000, len(toks)
-        for i, t in enumerate(toks):
-            if t > om.tok_beg:
-                delta, rlen = 2 * (t - om.tok_beg), i + 1
-        if len(got) >= len(ref) + rlen and got[len(ref):len(ref) + rlen] != toks[:rlen] and first_margin_problem is None:
-            k = next(i for i in range(rlen) if got[len(ref) + i] != toks[i])
-            first_margin_problem = float(margins[k])
-        ref += toks[:rlen]
-        seek += delta if delta > 0 else 3000
-        n_windows += 1
-        if first_margin_problem is not None:
-            break
-    assert n_windows >= 2
-    if first_margin_problem is None:
-        assert got == ref
-        assert res.text == b"".join(E.Context.token_text(_Ctx(eng), t) for t in got if t < om.tok_eot).decode().strip()
-    else:
-        assert first_margin_problem < 2 * TOL_LOGIT[1]
-    eng.close()

@@ -35,6 +35,7 @@ def test_two_ranks_on_one_gpu_match_the_single_process_engine(tmp_models):
     n_windows, tail = 5, 200000
     pcm = np.concatenate([synth.synth_audio(50 + w) for w in range(n_windows - 1)] + [synth.synth_audio(50 + n_windows - 1, tail)])
     eng = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_BF16, 2)
+    eng.set_decode_policy(temperature_inc=0.0)      # the sharded runner below is the staged T = 0 path
     eng.transcribe(E.AudioBuffer(pcm, 16000))
     ref, lens = eng.last_tokens(), [q[0] for q in eng.last_quality()]
     eng.close()

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert missing == []
     assert declared == set(E.EXPORTS), declared ^ set(E.EXPORTS)
-    assert lib.ohw_abi_version() == 1
+    assert lib.ohw_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_gpu():
