@@ -191,6 +191,9 @@ def main():
                 if len(grp) == 1:
                     out[grp[0]], _ = pst[0].greedy(B, p)
                     continue
+                dbg = os.environ.get("OHW_BENCH_DEBUG") == "1"
+                if dbg:
+                    tg0 = time.perf_counter(); full.sync(); tg1 = time.perf_counter()
                 for j in range(len(grp)):
                     dss[j].wait(full)
 
@@ -206,6 +209,8 @@ def main():
                     t.start()
                 for t in th:
                     t.join()
+                if dbg:
+                    print(f"[bench] group {grp}: front ends drained after {1e3 * (tg1 - tg0):.1f} ms of waiting, decodes {1e3 * (time.perf_counter() - tg1):.1f} ms", file=sys.stderr, flush=True)
                 if err:
                     raise err[0]
             if use_dist:

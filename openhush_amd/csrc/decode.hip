@@ -36,20 +36,43 @@ __device__ __forceinline__ void trace_mark(unsigned id, unsigned stage) {
 
 template <typename T>
 __global__ void embed_kernel(const T* __restrict__ emb, const float* __restrict__ pos, const int32_t* __restrict__ tok,
-                             const int32_t* __restrict__ n_past, float* __restrict__ x, int M, int n_new, int d) {
+                             const int32_t* __restrict__ n_past, float* __restrict__ x, T* __restrict__ x16, float* __restrict__ stat,
+                             int M, int n_new, int d) {
+  // one thread per group of 16 columns: besides the fp32 residual row it writes the 16-bit tiled copy and the group's
+  // (mean, sum of squared deviations) - what the post-norm GEMMs read instead of whole fp32 rows
   const int m = blockIdx.x;
   const int b = m / n_new, i = m % n_new;
   const int t = tok[m];
   const int pp = n_past[b] + i;
   const int64_t kblocks = d / 32;
-  for (int k = threadIdx.x; k < d; k += blockDim.x) {
-    const int64_t off = ((((int64_t)(t >> 4) * kblocks + (k >> 5)) * 64 + (t & 15) + 16 * ((k & 31) >> 3)) << 3) + (k & 7);
-    x[(int64_t)m * d + k] = (float)emb[off] + pos[(int64_t)pp * d + k];
+  const int n_grp = d / 16;
+  for (int g = threadIdx.x; g < n_grp; g += blockDim.x) {
+    float v[16];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int k = g * 16 + c;
+      const int64_t off = ((((int64_t)(t >> 4) * kblocks + (k >> 5)) * 64 + (t & 15) + 16 * ((k & 31) >> 3)) << 3) + (k & 7);
+      v[c] = (float)emb[off] + pos[(int64_t)pp * d + k];
+      sum += v[c];
+    }
+    const float mean = sum * (1.0f / 16.0f);
+    float m2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int k = g * 16 + c;
+      x[(int64_t)m * d + k] = v[c];
+      if (x16) x16[act_tiled_offset(m, k, d)] = (T)v[c];
+      m2 += (v[c] - mean) * (v[c] - mean);
+    }
+    if (stat) { stat[((int64_t)m * n_grp + g) * 2] = mean; stat[((int64_t)m * n_grp + g) * 2 + 1] = m2; }
   }
 }
 template <typename T>
-void launch_embed(const void* emb, const float* pos, const int32_t* tok, const int32_t* n_past, float* x, int M, int n_new, int d, hipStream_t s) {
-  hipLaunchKernelGGL((embed_kernel<T>), dim3(M), dim3(256), 0, s, (const T*)emb, pos, tok, n_past, x, M, n_new, d);
+void launch_embed(const void* emb, const float* pos, const int32_t* tok, const int32_t* n_past, float* x, void* x16, float* stat, int M,
+                  int n_new, int d, hipStream_t s) {
+  if (d % 32 != 0) throw Error(OHW_E_INVALID_ARG, "embed: d_model must be a multiple of 32");
+  hipLaunchKernelGGL((embed_kernel<T>), dim3(M), dim3(128), 0, s, (const T*)emb, pos, tok, n_past, x, (T*)x16, stat, M, n_new, d);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -78,7 +101,7 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   using vec8 = typename Ops::vec8;
   extern __shared__ __attribute__((aligned(16))) unsigned char dg_smem[];
   f32x4* part = (f32x4*)dg_smem;                                      // [8 waves][NT][2][64]
-  unsigned char* ylds = dg_smem + DG_WAVES * NT * 2 * 64 * 16;        // LN: [32][K*2 + 16] bytes
+  unsigned char* ylds = dg_smem + DG_WAVES * NT * 2 * 64 * 16;        // LN: [32][K*2 + 16] bytes; post-norm: f32 [32][2] mean, rstd
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt0 = blockIdx.x * NT;
   const int m0 = blockIdx.y * 16 * MT;
@@ -95,12 +118,45 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   const int ksplit = gridDim.z;
   const int k_lo = (int)((int64_t)kblocks * blockIdx.z / ksplit), k_hi = (int)((int64_t)kblocks * (blockIdx.z + 1) / ksplit);
   float resid_old[NT];
+  // producers of the post-norm path (stat_out != null, NT == 1): thread = (m-tile, row, column) so that the 16 columns of
+  // a row sit in 16 consecutive lanes (row statistics by shuffles, 64-byte row segments per store)
+  const bool stat_epi = EPI == DEPI_BIAS_RESID && NT == 1 && p.stat_out != nullptr && ksplit == 1;
+  const int s_mt = tid >> 8, s_r = (tid >> 4) & 15, s_c = tid & 15;
+  const int s_m = m0 + s_mt * 16 + s_r, s_n = nt0 * 16 + s_c;
+  const bool s_active = tid < 256 * MT;
   if (EPI == DEPI_BIAS_RESID && ksplit == 1) {
     // issue the read of the residual now: its latency hides under the weight stream
+    if (stat_epi) {
+      resid_old[0] = (s_active && s_m < p.M && s_n < p.N) ? ((const float*)p.out)[(int64_t)s_m * p.ld_out + s_n] : 0.f;
+    } else {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int n = (nt0 + t) * 16 + 4 * (e_ll >> 4) + e_reg;
-      resid_old[t] = (e_active && e_m < p.M && n < p.N) ? ((const float*)p.out)[(int64_t)e_m * p.ld_out + n] : 0.f;
+      for (int t = 0; t < NT; ++t) {
+        const int n = (nt0 + t) * 16 + 4 * (e_ll >> 4) + e_reg;
+        resid_old[t] = (e_active && e_m < p.M && n < p.N) ? ((const float*)p.out)[(int64_t)e_m * p.ld_out + n] : 0.f;
+      }
+    }
+  }
+  // post-norm consumers: the row statistics of this workgroup's 16 * MT rows from the published per-16-column tiles.
+  // 32 lanes per row; lane l merges tiles l, l + 32, l + 64 ... in order (Chan's update), then the xor tree 16 .. 1; only
+  // lane 0's result is used, so it is one fixed function of the tiles whatever MT is.  The loads go out before the weights'.
+  float pn_cnt[MT], pn_mean[MT], pn_m2[MT];
+  const bool pn = !LN && p.pn != 0;
+  if (pn) {
+    const int l32 = tid & 31, prow = tid >> 5;
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+      int m = m0 + q * 16 + prow;
+      if (m > p.M - 1) m = p.M - 1;
+      const float* st = p.stat_in + (int64_t)m * p.n_stat * 2;
+      float cnt = 0.f, mean = 0.f, m2 = 0.f;
+      for (int j = l32; j < p.n_stat; j += 32) {
+        const float mb = st[2 * j], qb = st[2 * j + 1];
+        const float nn = cnt + 16.f, delta = mb - mean;
+        mean += delta * (16.f / nn);
+        m2 += qb + delta * delta * (cnt * 16.f / nn);
+        cnt = nn;
+      }
+      pn_cnt[q] = cnt; pn_mean[q] = mean; pn_m2[q] = m2;
     }
   }
 
@@ -192,6 +248,30 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
     TRACE(16 + EPI * 2 + 1, 1);
   }
 
+  if (pn) {
+    float* pst = (float*)ylds;
+    const int l32 = tid & 31, prow = tid >> 5;
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+      float cnt = pn_cnt[q], mean = pn_mean[q], m2 = pn_m2[q];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        const float cb = __shfl_xor(cnt, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
+        const float nn = cnt + cb;
+        if (nn > 0.f) {
+          const float delta = mb - mean;
+          mean += delta * (cb / nn);
+          m2 += qb + delta * delta * (cnt * cb / nn);
+        }
+        cnt = nn;
+      }
+      if (l32 == 0) {
+        pst[(q * 16 + prow) * 2] = mean;
+        pst[(q * 16 + prow) * 2 + 1] = rsqrtf(m2 / (float)p.K + 1e-5f);
+      }
+    }
+    // visible to the epilogue behind the __syncthreads() that follows the partial-sum stores
+  }
   const T* __restrict__ x = (const T*)p.x;
   // activation tiles: k-block kk of the 16-row tile mt is the 1 KiB at ((mt * kblocks + kk) * 64 + lane) * 8 elements
   const T* x0 = LN ? nullptr : x + ((int64_t)(m0 >> 4) * kblocks * 64 + lane) * 8;
@@ -372,6 +452,37 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   // per n-tile: 2 m-tiles x 64 lanes x 4 regs = 512 outputs, one per thread
   // D layout: n = 4*(lane'>>4) + reg, m = mt*16 + (lane' & 15)
   const float* pp = (const float*)part;
+  if constexpr (EPI == DEPI_BIAS_RESID && NT == 1) {
+    if (stat_epi) {
+      if (!s_active) return;
+      const int ll = (s_c >> 2) * 16 + s_r, reg = s_c & 3;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < DG_WAVES; ++w) v += pp[((w * 2 + s_mt) * 64 + ll) * 4 + reg];
+      const bool ok = s_m < p.M && s_n < p.N;
+      if (p.bias && ok) v += p.bias[s_n];
+      const float xn = resid_old[0] + v;
+      if (ok) {
+        ((float*)p.out)[(int64_t)s_m * p.ld_out + s_n] = xn;
+        ((T*)p.x16_out)[act_tiled_offset(s_m, s_n, p.N)] = (T)xn;
+      }
+      // this tile's 16 columns of the row: mean and sum of squared deviations (two passes over registers)
+      float sum = xn;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      const float mean = sum * (1.0f / 16.0f);
+      float q2 = (xn - mean) * (xn - mean);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, 64);
+      if (s_c == 0 && s_m < p.M) {
+        float* so = p.stat_out + ((int64_t)s_m * (p.N >> 4) + nt0) * 2;
+        so[0] = mean; so[1] = q2;
+      }
+      TRACE(16 + EPI * 2, 3);
+      return;
+    }
+  }
+  const float* pnst = (const float*)ylds;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     float v = 0.f;
@@ -380,6 +491,10 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
     const int n = (nt0 + t) * 16 + 4 * (e_ll >> 4) + e_reg;
     const int m = e_m;
     if (!e_active || m >= p.M || n >= p.N || nt0 + t >= n_tiles) continue;
+    if (pn) {
+      const int r = e_mt * 16 + (e_ll & 15);
+      v = pnst[2 * r + 1] * (v - pnst[2 * r] * p.wsum[n]);
+    }
     if (p.bias) v += p.bias[n];
     if constexpr (EPI == DEPI_QKV) {
       const int d = p.d_model;
@@ -410,7 +525,7 @@ template <typename T, int EPI, bool LN, int NT, int MT>
 static void dec_gemm_launch(const DecGemmParams& p, hipStream_t s) {
   const int n_tiles = (p.N + 15) / 16;
   dim3 grid((n_tiles + NT - 1) / NT, (p.M + 16 * MT - 1) / (16 * MT), p.ksplit > 1 ? p.ksplit : 1);
-  const size_t smem = (size_t)DG_WAVES * NT * 2 * 64 * 16 + (LN ? (size_t)16 * MT * (p.K * 2 + 16) : 0);
+  const size_t smem = (size_t)DG_WAVES * NT * 2 * 64 * 16 + (LN ? (size_t)16 * MT * (p.K * 2 + 16) : 256);
   if (LN) ensure_dynamic_lds((const void*)dec_gemm_kernel<T, EPI, LN, NT, MT>, 160 * 1024);
   hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, LN, NT, MT>), grid, dim3(DG_THREADS), smem, s, p);
 }
@@ -428,6 +543,13 @@ static void dec_gemm_pick(const DecGemmParams& p, hipStream_t s) {
     // one m-tile per workgroup when that still fits one wave of CUs (and the hand-off path is not in use); a single
     // m-tile (batch <= 16) never takes the two-tile kernel, whose second tile would be loaded for nothing
     if (msplit && p.ksplit <= 1 && (mt == 1 || n_tiles * mt <= 2 * cus)) { dec_gemm_launch<T, EPI, LN, 1, 1>(p, s); return; }
+  }
+  if constexpr (!LN && (EPI == DEPI_QKV || EPI == DEPI_BIAS_T || EPI == DEPI_BIAS_GELU_T)) {
+    // post-norm consumers carry no LDS image: two workgroups share a CU, so the grid may be two waves of CUs
+    if (msplit && mt <= 2) {
+      if (n_tiles * mt <= 2 * cus) { dec_gemm_launch<T, EPI, LN, 1, 1>(p, s); return; }
+      if ((n_tiles + 1) / 2 * mt <= 2 * cus || mt == 1) { dec_gemm_launch<T, EPI, LN, 2, 1>(p, s); return; }
+    }
   }
   if constexpr (LN) {
     // one m-tile per workgroup halves the fp32 rows a workgroup normalises; pick the n-tiles per workgroup that keep
@@ -454,6 +576,9 @@ void launch_dec_gemm(const DecGemmParams& p, int epilogue, hipStream_t s) {
       throw Error(OHW_E_INVALID_ARG, "dec_gemm: split-K needs the RESID epilogue and a slab of tiles * ksplit * 2 KiB");
   }
   if (ln && (p.K % 64 != 0 || p.K > DG_LN_MAXK)) throw Error(OHW_E_INVALID_ARG, "dec_gemm: fused LayerNorm needs K <= 1280, K % 64 == 0");
+  if (p.pn && (ln || !p.stat_in || !p.wsum || p.n_stat * 16 != p.K)) throw Error(OHW_E_INVALID_ARG, "dec_gemm: post-norm needs statistics of K / 16 tiles per row and the weights' row sums");
+  if (p.stat_out && (epilogue != DEPI_BIAS_RESID || !p.x16_out || p.N % 32 != 0 || p.ksplit > 1))
+    throw Error(OHW_E_INVALID_ARG, "dec_gemm: statistics come from the unsplit RESID epilogue with N % 32 == 0");
   switch (epilogue) {
     case DEPI_QKV: if (ln) dec_gemm_pick<T, DEPI_QKV, true>(p, s); else dec_gemm_pick<T, DEPI_QKV, false>(p, s); break;
     case DEPI_BIAS_T: if (ln) dec_gemm_pick<T, DEPI_BIAS_T, true>(p, s); else dec_gemm_pick<T, DEPI_BIAS_T, false>(p, s); break;
@@ -1001,7 +1126,7 @@ void launch_sampler(const SamplerParams& p, hipStream_t s) {
 
 #define INST(T) \
   template void launch_dec_gemm<T>(const DecGemmParams&, int, hipStream_t); \
-  template void launch_embed<T>(const void*, const float*, const int32_t*, const int32_t*, float*, int, int, int, hipStream_t); \
+  template void launch_embed<T>(const void*, const float*, const int32_t*, const int32_t*, float*, void*, float*, int, int, int, hipStream_t); \
   template void launch_self_attn<T>(const void*, const void*, const void*, const int32_t*, void*, int, int, int, int, hipStream_t); \
   template void launch_cross_attn<T>(const void*, const void*, const void*, void*, int, int, int, int, float*, unsigned*, int, const int32_t*, hipStream_t);
 INST(bf16_t)

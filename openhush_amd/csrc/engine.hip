@@ -85,6 +85,8 @@ struct ohw_state {
   DevBuf xkv;      // T [2L][B][H][1500][64]
   DevBuf self_kv;  // T [L][2][B][H][n_text_ctx][64]
   DevBuf dx, dy, dq, da, df, logits;
+  DevBuf dx16, xstat;            // post-norm path: 16-bit tiled copy of the residual stream, per-16-column statistics
+  bool postnorm = true;
   DevBuf ks_slab, ks_ticket;   // split-K partial tiles and arrival tickets of the decoder's RESID GEMMs
   int ksplit_long = 1, ksplit_short = 1;
   int stream_cus = 0;            // CUs of the current stream's mask (0 = unrestricted)
@@ -95,6 +97,7 @@ struct ohw_state {
   DevBuf step_tok, n_past, tokens, n_cur, next_tok, done, n_done, sum_lp;
   DevBuf tok_lp, nosp_prob;        // per-token log-probabilities [B][max_tokens + 1], no-speech probability [B]
   DevBuf logit_bias;               // optional f32 [n_vocab] (ohw_state_set_logit_bias)
+  std::vector<float> bias_host;    // the same on the host: the temperature ladder samples there (host_engine.cpp)
   bool bias_on = false;
   int m_max = 0;
   int64_t logits_ld = 0;
@@ -173,6 +176,11 @@ void state_alloc(ohw_state* st) {
   // multiplied but never stored)
   const size_t m_tiles = ((size_t)st->m_max + 31) / 32 * 32;
   st->dy.alloc(m_tiles * dt * 2, true);
+  // post-norm decoder GEMMs (decode.hip): on unless OHW_DEC_POSTNORM=0 or a split-K knob is set (the split path publishes
+  // no statistics); dt must be a multiple of 32
+  st->postnorm = env_int("OHW_DEC_POSTNORM", 1, 0, 1) != 0 && dec_ksplit_long() == 1 && dec_ksplit_short() == 1 && dt % 32 == 0;
+  st->dx16.alloc(m_tiles * dt * 2, true);
+  st->xstat.alloc((size_t)st->m_max * (dt / 16) * 2 * 4, true);
   st->dq.alloc((size_t)st->m_max * dt * 2);
   st->da.alloc(m_tiles * dt * 2, true);
   st->df.alloc(m_tiles * 4 * dt * 2, true);
@@ -281,13 +289,20 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
   const int M = B * n_new;
   if (M > st->m_max) throw Error(OHW_E_INVALID_ARG, "decode: batch * n_new exceeds the state's capacity (8 tokens per window per call)");
   const int32_t* n_past = st->n_past.as<int32_t>();
-  launch_embed<T>(c->emb.p, c->dec_pos.as<float>(), tok_src ? tok_src : st->step_tok.as<int32_t>(), n_past, st->dx.as<float>(), M, n_new, d, s);
+  const bool pn = st->postnorm;
+  launch_embed<T>(c->emb.p, c->dec_pos.as<float>(), tok_src ? tok_src : st->step_tok.as<int32_t>(), n_past, st->dx.as<float>(),
+                  pn ? st->dx16.p : nullptr, pn ? st->xstat.as<float>() : nullptr, M, n_new, d, s);
   const int64_t kv_layer = (int64_t)st->max_batch * H * C * 64;      // elements per K (or V) cache of one layer
   const int64_t xkv_slab = (int64_t)B * H * Tn * 64;                 // cross K/V slab (batch of the last encode)
-  auto gemm = [&](const void* x, const LayerNormW* ln, const DevBuf& w, const DevBuf& bias, void* out, int N, int K, int epi, int64_t ld) {
+  auto gemm = [&](const void* x, const LayerNormW* ln, const DevBuf& w, const DevBuf& bias, void* out, int N, int K, int epi, int64_t ld,
+                  const DevBuf* wsum = nullptr) {
     DecGemmParams p{};
     p.x = x; p.w = w.p; p.bias = bias.p ? bias.as<float>() : nullptr; p.out = out;
     p.ln = ln ? 1 : 0;
+    if (ln && pn && wsum) {       // post-norm: the 16-bit tiled residual copy in, LayerNorm applied in the epilogue
+      p.x = st->dx16.p; p.ln = 0; p.pn = 1; p.n_stat = K / 16; p.stat_in = st->xstat.as<float>(); p.wsum = wsum->as<float>();
+    }
+    if (epi == DEPI_BIAS_RESID && pn && N == d) { p.x16_out = st->dx16.p; p.stat_out = st->xstat.as<float>(); }
     p.cu_budget = st->stream_cus;
     if (epi == DEPI_BIAS_RESID) {
       const int ks = K >= 2 * d ? st->ksplit_long : st->ksplit_short;
@@ -310,6 +325,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
     {  // LN1 + fused QKV projection; K/V go straight into the cache at each window's position
       DecGemmParams p{};
       p.x = st->dx.p; p.ln = 1; p.cu_budget = st->stream_cus;
+      if (pn) { p.x = st->dx16.p; p.ln = 0; p.pn = 1; p.n_stat = d / 16; p.stat_in = st->xstat.as<float>(); p.wsum = w.sqkv.as<float>(); }
       p.w = w.wqkv.p; p.bias = w.bqkv.as<float>(); p.out = st->dq.p;
       p.M = M; p.N = 3 * d; p.K = d; p.n_new = n_new; p.ld_out = d;
       p.k_cache = kc; p.v_cache = vc; p.n_past = n_past; p.d_model = d; p.n_head = H; p.n_ctx = C;
@@ -318,7 +334,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
     }
     launch_self_attn<T>(st->dq.p, kc, vc, n_past, st->da.p, M, n_new, H, C, s);
     gemm(st->da.p, nullptr, w.wo, w.bo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
-    gemm(st->dx.p, &w.lnx, w.wxq, w.bxq, st->dq.p, d, d, DEPI_BIAS_T, d);
+    gemm(st->dx.p, &w.lnx, w.wxq, w.bxq, st->dq.p, d, d, DEPI_BIAS_T, d, &w.sxq);
     {
       // algorithmic bytes: K and V of every (query row, head); the prompt pass streams them once per (window, head)
       // for all its rows (cross_attn_rows_kernel: same condition as launch_cross_attn)
@@ -329,7 +345,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
                            st->skip_done ? st->done.as<int32_t>() : nullptr, s);
     }
     gemm(st->da.p, nullptr, w.wxo, w.bxo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
-    gemm(st->dx.p, &w.ln2, w.w1, w.b1, st->df.p, 4 * d, d, DEPI_BIAS_GELU_T, 4 * d);
+    gemm(st->dx.p, &w.ln2, w.w1, w.b1, st->df.p, 4 * d, d, DEPI_BIAS_GELU_T, 4 * d, &w.s1);
     gemm(st->df.p, nullptr, w.w2, w.b2, st->dx.p, d, 4 * d, DEPI_BIAS_RESID, d);
   }
   launch_layernorm<T>(st->dx.as<float>(), c->dec_ln.g.as<float>(), c->dec_ln.b.as<float>(), st->dy.p, M, d, s, true);
@@ -511,6 +527,12 @@ int ohw_stream_sync(void* stream) {
 }
 
 int ohw_state_max_batch(const ohw_state* st) { return st ? st->max_batch : 0; }
+}  // extern "C"
+namespace ohw {
+// the state's logit bias as the host sampler needs it (null when none is set); library-internal
+const float* state_bias_host(const ohw_state* st) { return st && st->bias_on && !st->bias_host.empty() ? st->bias_host.data() : nullptr; }
+}
+extern "C" {
 const ohw_ctx* ohw_state_ctx(const ohw_state* st) { return st ? st->ctx : nullptr; }
 
 int ohw_mel(ohw_state* st, const float* pcm, int64_t pcm_stride, const int32_t* n_samples, int batch, int pcm_on_device,
@@ -766,10 +788,11 @@ int ohw_state_set_logit_bias(ohw_state* st, const float* bias, int n) {
     if (!st) throw Error(OHW_E_INVALID_ARG, "state is null");
     HIP_CHECK(hipSetDevice(st->ctx->device));
     HIP_CHECK(hipStreamSynchronize(st->stream));
-    if (!bias) { st->bias_on = false; return; }
+    if (!bias) { st->bias_on = false; st->bias_host.clear(); return; }
     if (n != st->ctx->hp.n_vocab) throw Error(OHW_E_INVALID_ARG, "logit bias: n must equal n_vocab");
     if (!st->logit_bias.p) st->logit_bias.alloc((size_t)n * 4);
     HIP_CHECK(hipMemcpy(st->logit_bias.p, bias, (size_t)n * 4, hipMemcpyHostToDevice));
+    st->bias_host.assign(bias, bias + n);
     st->bias_on = true;
   });
 }

@@ -24,6 +24,7 @@
 
 namespace ohw {
 extern thread_local std::string g_last_error;
+const float* state_bias_host(const ohw_state* st);
 }
 extern "C" const ohw_ctx* ohw_state_ctx(const ohw_state* st);
 using namespace ohw;
@@ -465,6 +466,8 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
             if (!live[(size_t)b]) continue;
             WindowRun& r = pass[(size_t)b];
             float lp = 0.f;
+            if (const float* bias = state_bias_host(st))          // the state's logit bias: the device sampler adds it itself
+              for (int i2 = 0; i2 < V; ++i2) logits[(size_t)b * V + i2] += bias[i2];
             const int32_t t = ohw_sample_host(e->ctx, &sp, &logits[(size_t)b * V], r.tok.data(), (int)r.tok.size(), T, rngs[(size_t)b], &lp, &r.nosp);
             if (t < 0) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: host sampler");
             r.tok.push_back(t); r.plog.push_back(lp);

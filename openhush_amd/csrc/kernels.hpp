@@ -14,6 +14,8 @@ template <typename T> void launch_convert_rows(const float* src, void* dst, int6
 template <typename T> void launch_repack_conv(const float* src, void* dst, int64_t d_out, int64_t c_in, int64_t c_pad, hipStream_t s);
 // decoder linear [N][K] f32 -> MFMA-fragment tiles T [Npad/16][K/32][64][8], rows >= N zero
 template <typename T> void launch_repack_tiled(const float* src, void* dst, int64_t N, int64_t n_pad, int64_t K, hipStream_t s);
+// wsum[n] = sum_k of the rounded 16-bit values of a fragment-tiled [N][K] matrix
+template <typename T> void launch_tiled_rowsum(const void* w_tiled, float* wsum, int64_t N, int64_t K, hipStream_t s);
 // fold a pre-LayerNorm's affine part into the linear layer that follows it (in place, f32 [N][K]):
 //   bias[n] += sum_k beta[k] * W[n][k];  W[n][k] *= gamma[k]      so that  LN(x) W^T + b == ((x - mean) rstd) W'^T + b'
 void launch_fold_ln(float* w, float* bias, const float* gamma, const float* beta, int64_t N, int64_t K, hipStream_t s);
@@ -65,12 +67,23 @@ struct DecGemmParams {
   int32_t slab_bytes;
   float* slab;                      // f32 [tiles][ksplit][512]
   unsigned* ticket;                 // [tiles], zero between launches (the kernel re-arms it)
+  // post-norm path (ln == 0, pn != 0): x is the 16-bit tiled copy of the residual stream and the LayerNorm is applied AFTER
+  // the product: out = rstd[m] * (x W^T - mean[m] * wsum[n]) + bias[n], mean / rstd from the per-16-column statistics the
+  // producers of the residual stream publish (no full-row read, no LayerNorm prologue, no LDS image)
+  int32_t pn;
+  int32_t n_stat;                   // statistics tiles per row (d_model / 16)
+  const float* stat_in;             // f32 [M][n_stat][2]: mean and sum of squared deviations of 16 columns
+  const float* wsum;                // f32 [N]
+  // DEPI_BIAS_RESID producers: besides x (f32) also its 16-bit tiled copy and this tile's statistics (all null: off)
+  void* x16_out;                    // T tiles [ceil(M/16)][N/32][64][8]
+  float* stat_out;                  // f32 [M][N/16][2]
 };
 template <typename T> void launch_dec_gemm(const DecGemmParams& p, int epilogue, hipStream_t s);
 
 // x f32 [M][d] = token_embedding[tok[m]] + pos_emb[n_past[m / n_new] + m % n_new]
+// x16 / stat (may be null): the 16-bit tiled copy and the per-16-column statistics of the post-norm path
 template <typename T> void launch_embed(const void* emb_tiled, const float* pos, const int32_t* tok, const int32_t* n_past,
-                                        float* x, int M, int n_new, int d, hipStream_t s);
+                                        float* x, void* x16, float* stat, int M, int n_new, int d, hipStream_t s);
 // causal self-attention of the new tokens against the cache.  q T [M][d] -> out T, activation-tile order
 template <typename T> void launch_self_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* n_past,
                                             void* out, int M, int n_new, int n_head, int n_ctx, hipStream_t s);

@@ -104,6 +104,9 @@ struct Placer {
     launch_repack_tiled<T>((float*)pl.w[F_WXQ].p, l.wxq.p, dt, dt, dt, s);
     launch_fold_ln((float*)pl.w[F_W1].p, l.b1.as<float>(), l.ln2.g.as<float>(), l.ln2.b.as<float>(), 4 * dt, dt, s);
     launch_repack_tiled<T>((float*)pl.w[F_W1].p, l.w1.p, 4 * dt, 4 * dt, dt, s);
+    launch_tiled_rowsum<T>(l.wqkv.p, l.sqkv.as<float>(), 3 * dt, dt, s);
+    launch_tiled_rowsum<T>(l.wxq.p, l.sxq.as<float>(), dt, dt, s);
+    launch_tiled_rowsum<T>(l.w1.p, l.s1.as<float>(), 4 * dt, dt, s);
     HIP_CHECK(hipStreamSynchronize(s));
     for (auto& b : pl.w) b.release();
   }
@@ -161,6 +164,7 @@ struct Placer {
       A(l.wxo, (size_t)dt * dt * e); A(l.bxo, dt * 4);
       A(l.w1, (size_t)4 * dt * dt * e); A(l.b1, (size_t)4 * dt * 4);
       A(l.w2, (size_t)4 * dt * dt * e); A(l.b2, dt * 4);
+      A(l.sqkv, (size_t)3 * dt * 4); A(l.sxq, dt * 4); A(l.s1, (size_t)4 * dt * 4);
     }
     A(c->dec_ln.g, dt * 4); A(c->dec_ln.b, dt * 4);
   }

@@ -50,6 +50,7 @@ struct DecLayerW {
   DevBuf wo, bo;      // tiled
   DevBuf wxq, bxq, wxo, bxo;
   DevBuf w1, b1, w2, b2;
+  DevBuf sqkv, sxq, s1;   // f32 row sums of the folded, rounded wqkv / wxq / w1 (post-norm GEMMs)
 };
 
 }  // namespace ohw

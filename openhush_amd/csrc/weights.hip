@@ -89,6 +89,27 @@ void launch_repack_tiled(const float* src, void* dst, int64_t N, int64_t n_pad, 
   HIP_CHECK(hipGetLastError());
 }
 
+// wsum[n] = sum_k W[n][k] over the ROUNDED 16-bit values of a fragment-tiled matrix (what the MFMA multiplies): the
+// decoder's post-norm GEMMs compute rstd * (x W^T - mean * wsum) instead of normalising x first (decode.hip)
+template <typename T>
+__global__ __launch_bounds__(256) void tiled_rowsum_kernel(const T* __restrict__ w, float* __restrict__ wsum, int64_t N, int64_t K) {
+  __shared__ float red[4];
+  const int64_t n = blockIdx.x;
+  const int64_t kblocks = K / 32;
+  float acc = 0.f;
+  for (int64_t k = threadIdx.x; k < K; k += 256)
+    acc += (float)w[((((n >> 4) * kblocks + (k >> 5)) * 64 + (n & 15) + 16 * ((k & 31) >> 3)) << 3) + (k & 7)];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) wsum[n] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+template <typename T>
+void launch_tiled_rowsum(const void* w, float* wsum, int64_t N, int64_t K, hipStream_t s) {
+  hipLaunchKernelGGL((tiled_rowsum_kernel<T>), dim3((unsigned)N), dim3(256), 0, s, (const T*)w, wsum, N, K);
+  HIP_CHECK(hipGetLastError());
+}
+
 __global__ __launch_bounds__(256) void fold_ln_kernel(float* __restrict__ w, float* __restrict__ bias, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int64_t K) {
   __shared__ float red[4];
@@ -109,7 +130,8 @@ void launch_fold_ln(float* w, float* bias, const float* gamma, const float* beta
 #define INST(T) \
   template void launch_convert_rows<T>(const float*, void*, int64_t, int64_t, int64_t, hipStream_t); \
   template void launch_repack_conv<T>(const float*, void*, int64_t, int64_t, int64_t, hipStream_t);  \
-  template void launch_repack_tiled<T>(const float*, void*, int64_t, int64_t, int64_t, hipStream_t);
+  template void launch_repack_tiled<T>(const float*, void*, int64_t, int64_t, int64_t, hipStream_t); \
+  template void launch_tiled_rowsum<T>(const void*, float*, int64_t, int64_t, hipStream_t);
 INST(bf16_t)
 INST(f16_t)
 #undef INST

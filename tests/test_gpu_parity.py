@@ -525,3 +525,34 @@ def test_language_detection_matches_oracle(E, oracle, models):
         top2 = np.sort(lg)[-2:]
         assert ids[b] == int(lg.argmax()) or top2[1] - top2[0] < 2 * TOL_LOGIT[1]
     assert E.lang_id_to_code(int(ids[0])) != ""
+
+
+def test_post_norm_gemms_match_the_layernorm_prologue(E, oracle, models, monkeypatch):
+    """The decoder's LayerNorm -> projection pairs run as rstd * (x16 W^T - mean * wsum) + b on the 16-bit tiled copy of the
+    residual stream with per-16-column statistics published by its producers (OHW_DEC_POSTNORM=1, the default), or with the
+    LayerNorm of the fp32 rows in the GEMM's prologue (=0).  Both against the oracle, and against each other."""
+    _, _, om, ctxs = models
+    pcm, ns = _pcm_batch()
+    toks = [ctxs[1].tok.sot, ctxs[1].tok.sot + 1, ctxs[1].tok.transcribe, 60, 70, 80, 90]
+    out = {}
+    for dt in (0, 1):
+        for mode in ("1", "0"):
+            monkeypatch.setenv("OHW_DEC_POSTNORM", mode)          # read when a state is created
+            st = E.State(ctxs[dt], 3)
+            mel = st.mel(pcm, ns, E.OHW_MEL_REFLECT)
+            st.encode(3)
+            lg = [st.decode(np.tile(np.asarray(toks[:3], np.int32), (3, 1)), [0, 0, 0])]
+            for i in range(3, len(toks)):
+                lg.append(st.decode(np.full((3, 1), toks[i], np.int32), [i, i, i]))
+            out[(dt, mode)] = np.stack(lg)
+        ref = []
+        for b in range(3):
+            s = oracle.State(om)
+            s.set_encoder_output(om.encode(mel[b]))
+            ref.append(s.decode(toks, 0, all_pos=True)[2:])
+        ref = np.stack(ref, axis=1)                                # [step][window][vocab]
+        for mode in ("1", "0"):
+            err = float(np.abs(out[(dt, mode)] - ref).max())
+            print(f"dtype {dt} post-norm {mode}: worst logit error vs oracle {err:.4f}")
+            assert err < TOL_LOGIT[dt], (dt, mode, err)
+        assert float(np.abs(out[(dt, "1")] - out[(dt, "0")]).max()) < TOL_LOGIT[dt]
