@@ -292,6 +292,29 @@ int ohw_engine_benchmark(ohw_engine* e, float safety_margin, float* overhead_sec
 void ohw_engine_free(ohw_engine* e);
 ohw_state* ohw_engine_state(ohw_engine* e);
 ohw_ctx* ohw_engine_ctx(ohw_engine* e);
+/* ---- multi-GPU pool behind the boundary.  The reference has no multi-GPU code, only the intent:
+ *      requirement F14 "distribute transcriptions across multiple GPUs on a single machine" (reference REQUIREMENTS.md:26)
+ *      and the config keys `[gpu] auto_detect / devices` that today do nothing (src/config.rs:921-929).  One engine and
+ *      one host thread per listed device.  The model file is read ONCE (device_ids[0]); its resident weight arena reaches
+ *      the other devices in one broadcast over xGMI: RCCL (ncclCommInitAll + ncclBroadcast, loaded with dlopen at run
+ *      time) or peer-to-peer copies when RCCL cannot be loaded, OHW_POOL_BCAST=peer is set, or a device is listed twice.
+ *      ohw_pool_transcribe has ohw_engine_transcribe's contract; the fixed 30 s windows of the recording are dealt
+ *      round-robin (window w -> device w mod n) with no collective in the data path, results gathered on the host in
+ *      recording order (the seek-loop window mode is sequential and runs on device_ids[0] alone). ----------------- */
+typedef struct ohw_pool ohw_pool;
+int ohw_pool_create(const char* model_path, const char* language, int translate, const int* device_ids, int n_devices,
+                    int dtype, int max_batch, ohw_pool** out);
+int ohw_pool_transcribe(ohw_pool* p, const float* samples, int64_t n, uint32_t sample_rate, char* text_buf, size_t text_cap,
+                        char* language_out, uint64_t* duration_ms, ohw_audio_info* info);
+int ohw_pool_last_text(ohw_pool* p, const char** text, size_t* len);
+int ohw_pool_last_tokens(ohw_pool* p, const int32_t** tokens, int* n);
+int ohw_pool_last_quality(ohw_pool* p, const ohw_window_quality** q, int* n_windows);
+int ohw_pool_set_decode_policy(ohw_pool* p, const ohw_decode_policy* q);
+int ohw_pool_n_devices(const ohw_pool* p);
+const char* ohw_pool_broadcast_kind(const ohw_pool* p);   /* "none" (one device), "rccl" or "peer" */
+ohw_engine* ohw_pool_engine(ohw_pool* p, int i);           /* the i-th device's engine (borrowed) */
+void ohw_pool_free(ohw_pool* p);
+
 /* lang id -> ISO code ("unknown" outside 0..98): reference lang_id_to_code :627-731               */
 const char* ohw_lang_id_to_code(int32_t id);
 /* ISO code -> lang id, -1 if unknown */

@@ -121,13 +121,19 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   // producers of the post-norm path (stat_out != null, NT == 1): thread = (m-tile, row, column) so that the 16 columns of
   // a row sit in 16 consecutive lanes (row statistics by shuffles, 64-byte row segments per store)
   const bool stat_epi = EPI == DEPI_BIAS_RESID && NT == 1 && p.stat_out != nullptr && ksplit == 1;
-  const int s_mt = tid >> 8, s_r = (tid >> 4) & 15, s_c = tid & 15;
+  const int s_mt = tid >> 7, s_r = (tid >> 3) & 15, s_c = (tid & 7) * 2;      // two adjacent columns per thread
   const int s_m = m0 + s_mt * 16 + s_r, s_n = nt0 * 16 + s_c;
-  const bool s_active = tid < 256 * MT;
+  const bool s_active = tid < 128 * MT;
+  float resid_old2 = 0.f;
   if (EPI == DEPI_BIAS_RESID && ksplit == 1) {
     // issue the read of the residual now: its latency hides under the weight stream
     if (stat_epi) {
-      resid_old[0] = (s_active && s_m < p.M && s_n < p.N) ? ((const float*)p.out)[(int64_t)s_m * p.ld_out + s_n] : 0.f;
+      if (s_active && s_m < p.M && s_n < p.N) {
+        const float2 r2 = *(const float2*)((const float*)p.out + (int64_t)s_m * p.ld_out + s_n);
+        resid_old[0] = r2.x; resid_old2 = r2.y;
+      } else {
+        resid_old[0] = 0.f;
+      }
     } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -139,24 +145,24 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   // post-norm consumers: the row statistics of this workgroup's 16 * MT rows from the published per-16-column tiles.
   // 32 lanes per row; lane l merges tiles l, l + 32, l + 64 ... in order (Chan's update), then the xor tree 16 .. 1; only
   // lane 0's result is used, so it is one fixed function of the tiles whatever MT is.  The loads go out before the weights'.
-  float pn_cnt[MT], pn_mean[MT], pn_m2[MT];
+  constexpr int PN_TILES = 4;                  // statistics tiles per lane: rows of up to 4 * 32 * 16 = 2048 columns
+  float pn_mb[MT][PN_TILES], pn_qb[MT][PN_TILES];
   const bool pn = !LN && p.pn != 0;
   if (pn) {
+    // only the loads here (clamped index, unconditional): they are needed in the epilogue, not before - merging them now
+    // would put their round trip in front of the weight stream
     const int l32 = tid & 31, prow = tid >> 5;
 #pragma unroll
     for (int q = 0; q < MT; ++q) {
       int m = m0 + q * 16 + prow;
       if (m > p.M - 1) m = p.M - 1;
-      const float* st = p.stat_in + (int64_t)m * p.n_stat * 2;
-      float cnt = 0.f, mean = 0.f, m2 = 0.f;
-      for (int j = l32; j < p.n_stat; j += 32) {
-        const float mb = st[2 * j], qb = st[2 * j + 1];
-        const float nn = cnt + 16.f, delta = mb - mean;
-        mean += delta * (16.f / nn);
-        m2 += qb + delta * delta * (cnt * 16.f / nn);
-        cnt = nn;
+      const float2* st = (const float2*)p.stat_in + (int64_t)m * p.n_stat;
+#pragma unroll
+      for (int u = 0; u < PN_TILES; ++u) {
+        const int j = l32 + 32 * u;
+        const float2 t2 = st[j < p.n_stat ? j : p.n_stat - 1];
+        pn_mb[q][u] = t2.x; pn_qb[q][u] = t2.y;
       }
-      pn_cnt[q] = cnt; pn_mean[q] = mean; pn_m2[q] = m2;
     }
   }
 
@@ -248,30 +254,6 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
     TRACE(16 + EPI * 2 + 1, 1);
   }
 
-  if (pn) {
-    float* pst = (float*)ylds;
-    const int l32 = tid & 31, prow = tid >> 5;
-#pragma unroll
-    for (int q = 0; q < MT; ++q) {
-      float cnt = pn_cnt[q], mean = pn_mean[q], m2 = pn_m2[q];
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-        const float cb = __shfl_xor(cnt, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
-        const float nn = cnt + cb;
-        if (nn > 0.f) {
-          const float delta = mb - mean;
-          mean += delta * (cb / nn);
-          m2 += qb + delta * delta * (cnt * cb / nn);
-        }
-        cnt = nn;
-      }
-      if (l32 == 0) {
-        pst[(q * 16 + prow) * 2] = mean;
-        pst[(q * 16 + prow) * 2 + 1] = rsqrtf(m2 / (float)p.K + 1e-5f);
-      }
-    }
-    // visible to the epilogue behind the __syncthreads() that follows the partial-sum stores
-  }
   const T* __restrict__ x = (const T*)p.x;
   // activation tiles: k-block kk of the 16-row tile mt is the 1 KiB at ((mt * kblocks + kk) * 64 + lane) * 8 elements
   const T* x0 = LN ? nullptr : x + ((int64_t)(m0 >> 4) * kblocks * 64 + lane) * 8;
@@ -399,6 +381,41 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
     for (; kb < k_hi; kb += DG_WAVES) run(std::integral_constant<int, 1>{}, kb);
   }
 
+  if (pn) {
+    // row statistics from the tiles loaded at the start: lane l merges tiles l, l + 32, l + 64 ... in order (Chan's
+    // update), then the xor tree 16 .. 1; only lane 0's result is used - one fixed function of the tiles whatever MT is
+    float* pst = (float*)ylds;
+    const int l32 = tid & 31, prow = tid >> 5;
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+      float cnt = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int u = 0; u < PN_TILES; ++u) {
+        if (l32 + 32 * u < p.n_stat) {
+          const float nn = cnt + 16.f, delta = pn_mb[q][u] - mean;
+          mean += delta * (16.f / nn);
+          m2 += pn_qb[q][u] + delta * delta * (cnt * 16.f / nn);
+          cnt = nn;
+        }
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        const float cb = __shfl_xor(cnt, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
+        const float nn = cnt + cb;
+        if (nn > 0.f) {
+          const float delta = mb - mean;
+          mean += delta * (cb / nn);
+          m2 += qb + delta * delta * (cnt * cb / nn);
+        }
+        cnt = nn;
+      }
+      if (l32 == 0) {
+        pst[(q * 16 + prow) * 2] = mean;
+        pst[(q * 16 + prow) * 2 + 1] = rsqrtf(m2 / (float)p.K + 1e-5f);
+      }
+    }
+    // visible to the epilogue behind the __syncthreads() that follows the partial-sum stores
+  }
   TRACE(16 + EPI * 2 + (LN ? 1 : 0), 2);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -455,29 +472,29 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
   if constexpr (EPI == DEPI_BIAS_RESID && NT == 1) {
     if (stat_epi) {
       if (!s_active) return;
-      const int ll = (s_c >> 2) * 16 + s_r, reg = s_c & 3;
-      float v = 0.f;
+      const int ll = (s_c >> 2) * 16 + s_r, reg = s_c & 3;          // s_c even: both columns in one accumulator register pair
+      float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-      for (int w = 0; w < DG_WAVES; ++w) v += pp[((w * 2 + s_mt) * 64 + ll) * 4 + reg];
+      for (int w = 0; w < DG_WAVES; ++w) {
+        const float2 pv = *(const float2*)&pp[((w * 2 + s_mt) * 64 + ll) * 4 + reg];
+        v0 += pv.x; v1 += pv.y;
+      }
       const bool ok = s_m < p.M && s_n < p.N;
-      if (p.bias && ok) v += p.bias[s_n];
-      const float xn = resid_old[0] + v;
+      if (p.bias && ok) { v0 += p.bias[s_n]; v1 += p.bias[s_n + 1]; }
+      const float x0 = resid_old[0] + v0, x1 = resid_old2 + v1;
       if (ok) {
-        ((float*)p.out)[(int64_t)s_m * p.ld_out + s_n] = xn;
-        ((T*)p.x16_out)[act_tiled_offset(s_m, s_n, p.N)] = (T)xn;
+        *(float2*)((float*)p.out + (int64_t)s_m * p.ld_out + s_n) = float2{x0, x1};
+        *(unsigned*)((T*)p.x16_out + act_tiled_offset(s_m, s_n, p.N)) = pack2<T>(x0, x1);
       }
-      // this tile's 16 columns of the row: mean and sum of squared deviations (two passes over registers)
-      float sum = xn;
+      // this tile's 16 columns of the row (8 lanes x 2): mean and sum of squared deviations, two passes over registers
+      float sum = x0 + x1;
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
       const float mean = sum * (1.0f / 16.0f);
-      float q2 = (xn - mean) * (xn - mean);
+      float q2 = (x0 - mean) * (x0 - mean) + (x1 - mean) * (x1 - mean);
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, 64);
-      if (s_c == 0 && s_m < p.M) {
-        float* so = p.stat_out + ((int64_t)s_m * (p.N >> 4) + nt0) * 2;
-        so[0] = mean; so[1] = q2;
-      }
+      for (int o = 4; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, 64);
+      if (s_c == 0 && s_m < p.M) *(float2*)(p.stat_out + ((int64_t)s_m * (p.N >> 4) + nt0) * 2) = float2{mean, q2};
       TRACE(16 + EPI * 2, 3);
       return;
     }
@@ -576,7 +593,7 @@ void launch_dec_gemm(const DecGemmParams& p, int epilogue, hipStream_t s) {
       throw Error(OHW_E_INVALID_ARG, "dec_gemm: split-K needs the RESID epilogue and a slab of tiles * ksplit * 2 KiB");
   }
   if (ln && (p.K % 64 != 0 || p.K > DG_LN_MAXK)) throw Error(OHW_E_INVALID_ARG, "dec_gemm: fused LayerNorm needs K <= 1280, K % 64 == 0");
-  if (p.pn && (ln || !p.stat_in || !p.wsum || p.n_stat * 16 != p.K)) throw Error(OHW_E_INVALID_ARG, "dec_gemm: post-norm needs statistics of K / 16 tiles per row and the weights' row sums");
+  if (p.pn && (ln || !p.stat_in || !p.wsum || p.n_stat * 16 != p.K || p.n_stat > 128)) throw Error(OHW_E_INVALID_ARG, "dec_gemm: post-norm needs statistics of K / 16 tiles per row and the weights' row sums");
   if (p.stat_out && (epilogue != DEPI_BIAS_RESID || !p.x16_out || p.N % 32 != 0 || p.ksplit > 1))
     throw Error(OHW_E_INVALID_ARG, "dec_gemm: statistics come from the unsplit RESID epilogue with N % 32 == 0");
   switch (epilogue) {

@@ -56,25 +56,7 @@ int guard(F&& f) {
 }
 }  // namespace
 
-struct ohw_engine {
-  ohw_ctx* ctx = nullptr;
-  ohw_state* state = nullptr;
-  std::string language;
-  bool translate = false;
-  int max_batch = 1;
-  int window_mode = OHW_WINDOW_FIXED;
-  std::vector<int32_t> last_tokens;
-  std::string last_text;
-  std::vector<ohw_window_quality> last_quality;
-  // two batches in flight for audio longer than max_batch windows (include/ohw.h, ohw_stream_create): a second state
-  // and three streams, made on first use; enc_cus = 0 keeps the batches strictly one after the other
-  ohw_state* state2 = nullptr;
-  void* s_full = nullptr; void* s_enc = nullptr; void* s_dec = nullptr;
-  int enc_cus = 96;
-  int device = 0;
-  ohw_decode_policy policy{0.2f, 2.4f, -1.0f, 0.6f};
-  std::vector<int32_t> last_trace;   // every decode pass of the last transcribe: {window, temperature * 1000, n, tokens...}
-};
+#include "host_engine.hpp"
 
 namespace {
 // ---- whisper.cpp's per-window bookkeeping (whisper_full_with_state as recalled) ---------
@@ -165,232 +147,23 @@ std::vector<float> ladder(const ohw_decode_policy& q) {
 }
 }  // namespace
 
-extern "C" {
+namespace ohw {
 
-const char* ohw_lang_id_to_code(int32_t id) { return (id >= 0 && id < 99) ? kLangs[id] : "unknown"; }
-
-int32_t ohw_lang_code_to_id(const char* code) {
-  if (!code) return -1;
-  for (int i = 0; i < 99; ++i)
-    if (std::strcmp(code, kLangs[i]) == 0) return i;
-  return -1;
+ohw_engine* engine_wrap_ctx(ohw_ctx* ctx, const std::string& language, bool translate, int max_batch, int device) {
+  std::unique_ptr<ohw_engine> e(new ohw_engine());
+  e->language = language;
+  e->translate = translate;
+  e->max_batch = std::max(1, max_batch);
+  e->device = device;
+  if (const char* ev = getenv("OHW_ENGINE_ENC_CUS")) e->enc_cus = std::max(0, atoi(ev));
+  const int rc = ohw_state_create(ctx, e->max_batch, &e->state);
+  if (rc != OHW_OK) throw Error(rc == OHW_E_OOM ? rc : OHW_E_LOAD_FAILED, "Failed to create state: " + g_last_error);
+  e->ctx = ctx;
+  return e.release();
 }
 
-int ohw_validate_audio(const float* samples, int64_t n, uint32_t sample_rate, ohw_audio_info* info) {
-  if (!info) return OHW_E_INVALID_ARG;
-  std::memset(info, 0, sizeof *info);
-  auto fail = [&](int code) { info->error = code; return OHW_E_VALIDATION; };
-  if (n <= 0 || !samples) return fail(OHW_AUDIO_EMPTY);                      // validation.rs:51-53
-  if (sample_rate != 16000u) return fail(OHW_AUDIO_BAD_RATE);               // :56-61
-  const float duration = (float)n / (float)sample_rate;                     // :64
-  info->duration_secs = duration;
-  info->sample_count = n;
-  if (duration > 7200.0f) return fail(OHW_AUDIO_TOO_LONG);                  // :67-72 (before the scan)
-  if (duration < 0.1f) return fail(OHW_AUDIO_TOO_SHORT);                    // :74-79
-  float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
-  double ss = 0.0;
-  int64_t n_nan = 0, n_inf = 0;
-  for (int64_t i = 0; i < n; ++i) {                                         // :88-98
-    const float v = samples[i];
-    if (std::isnan(v)) ++n_nan;
-    else if (std::isinf(v)) ++n_inf;
-    else { mn = std::min(mn, v); mx = std::max(mx, v); ss += (double)v * (double)v; }
-  }
-  info->nan_count = n_nan;
-  info->inf_count = n_inf;
-  if (n_nan > 0) return fail(OHW_AUDIO_NAN);                                // :100-102
-  if (n_inf > 0) return fail(OHW_AUDIO_INF);                                // :104-106
-  info->min_value = mn;
-  info->max_value = mx;
-  info->rms = (float)std::sqrt(ss / (double)n);                             // :109
-  info->error = OHW_AUDIO_OK;
-  return OHW_OK;
-}
-
-// Host-side logits filter: whisper.cpp's whisper_process_logits with the defaults the reference inherits
-// (SURVEY.md A4.6, Appendix A).  Same rule order as the device sampler in decode.hip.  Masks `logits` in place
-// (timestamp-mass rule included) and returns the log-sum-exp taken BEFORE that rule, as whisper.cpp's logprobs are.
-static float filter_logits(const ohw_ctx* ctx, const ohw_sample_params* p, float* logits, const int32_t* cur, int n_cur) {
-  const ohw_special_tokens& t = ctx->tok;
-  const int V = ctx->hp.n_vocab;
-  const float NEG = -INFINITY;
-  const bool is_initial = n_cur == 0;
-  if (p->suppress_blank && is_initial) {
-    logits[t.eot] = NEG;
-    if (t.blank >= 0) logits[t.blank] = NEG;
-  }
-  logits[t.no_timestamps] = NEG;
-  logits[t.sot] = NEG; logits[t.nosp] = NEG; logits[t.translate] = NEG; logits[t.transcribe] = NEG;
-  logits[t.prev] = NEG; logits[t.solm] = NEG;
-  for (int i = 0; i < t.n_langs; ++i) logits[t.sot + 1 + i] = NEG;
-  if (p->force_len > 0 && n_cur < p->force_len) logits[t.eot] = NEG;
-  if (p->no_timestamps) {
-    for (int i = t.timestamp_begin; i < V; ++i) logits[i] = NEG;
-  } else {
-    const bool last_ts = n_cur > 0 && cur[n_cur - 1] >= t.timestamp_begin;
-    const bool penult_ts = n_cur < 2 || cur[n_cur - 2] >= t.timestamp_begin;
-    if (last_ts) {
-      if (penult_ts) { for (int i = t.timestamp_begin; i < V; ++i) logits[i] = NEG; }
-      else { for (int i = 0; i < t.eot; ++i) logits[i] = NEG; }
-    }
-    if (is_initial && p->max_initial_ts > 0)
-      for (int i = t.timestamp_begin + p->max_initial_ts + 1; i < V; ++i) logits[i] = NEG;
-    int last_seen = -1;
-    for (int i = n_cur - 1; i >= 0; --i) if (cur[i] >= t.timestamp_begin) { last_seen = cur[i]; break; }
-    if (last_seen >= 0) for (int i = t.timestamp_begin; i < last_seen; ++i) logits[i] = NEG;
-  }
-  float mx = NEG;
-  for (int i = 0; i < V; ++i) mx = std::max(mx, logits[i]);
-  double sum = 0.0, ts_sum = 0.0;
-  float text_max = NEG;
-  for (int i = 0; i < V; ++i) {
-    if (!(logits[i] > NEG)) continue;
-    const double e = std::exp((double)(logits[i] - mx));
-    sum += e;
-    if (i >= t.timestamp_begin) ts_sum += e; else text_max = std::max(text_max, logits[i]);
-  }
-  const float lse = mx + (float)std::log(sum);
-  if (!p->no_timestamps && ts_sum > 0.0) {
-    const float ts_lp = mx + (float)std::log(ts_sum) - lse;
-    if (ts_lp > text_max - lse) for (int i = 0; i < t.timestamp_begin; ++i) logits[i] = NEG;
-  }
-  return lse;
-}
-
-int32_t ohw_sample_greedy_host(const ohw_ctx* ctx, const ohw_sample_params* p, float* logits, const int32_t* cur, int n_cur,
-                               float* logprob_out) {
-  if (!ctx || !p || !logits) return -1;
-  const float lse = filter_logits(ctx, p, logits, cur, n_cur);
-  const int V = ctx->hp.n_vocab;
-  int best = 0;
-  float bv = -INFINITY;
-  for (int i = 0; i < V; ++i) if (logits[i] > bv) { bv = logits[i]; best = i; }
-  if (logprob_out) *logprob_out = bv - lse;
-  return best;
-}
-
-// whisper.cpp's decoders draw with std::mt19937 (seeded 0 once per whisper_full call) through
-// std::discrete_distribution over exp(logprobs): whisper_sample_token with best = false (SURVEY.md Appendix A)
-struct ohw_rng { std::mt19937 gen; };
-ohw_rng* ohw_rng_new(uint32_t seed) { return new (std::nothrow) ohw_rng{std::mt19937(seed)}; }
-void ohw_rng_free(ohw_rng* r) { delete r; }
-
-int32_t ohw_sample_host(const ohw_ctx* ctx, const ohw_sample_params* p, float* logits, const int32_t* cur, int n_cur, float temperature,
-                        ohw_rng* rng, float* logprob_out, float* no_speech_prob_out) {
-  if (!ctx || !p || !logits) return -1;
-  const int V = ctx->hp.n_vocab;
-  if (temperature > 0.0f) for (int i = 0; i < V; ++i) logits[i] /= temperature;
-  if (no_speech_prob_out && n_cur == 0) {
-    float mx = -INFINITY;
-    for (int i = 0; i < V; ++i) mx = std::max(mx, logits[i]);
-    double sum = 0.0;
-    for (int i = 0; i < V; ++i) sum += std::exp((double)(logits[i] - mx));
-    *no_speech_prob_out = (float)std::exp((double)(logits[ctx->tok.nosp] - mx) - std::log(sum));
-  }
-  if (!(temperature > 0.0f)) return ohw_sample_greedy_host(ctx, p, logits, cur, n_cur, logprob_out);
-  if (!rng) return -1;
-  const float lse = filter_logits(ctx, p, logits, cur, n_cur);
-  std::vector<float> probs((size_t)V);
-  for (int i = 0; i < V; ++i) probs[(size_t)i] = logits[i] > -INFINITY ? std::exp(logits[i] - lse) : 0.0f;
-  std::discrete_distribution<> dist(probs.begin(), probs.end());
-  const int id = dist(rng->gen);
-  if (logprob_out) *logprob_out = logits[id] - lse;
-  return id;
-}
-
-int ohw_detect_language(ohw_state* st, int batch, int32_t* lang_ids_out, float* lang_probs_out) {
-  return guard([&] {
-    if (!st || !lang_ids_out || batch < 1) throw Error(OHW_E_INVALID_ARG, "bad argument");
-    const ohw_ctx* ctx = ohw_state_ctx(st);
-    const ohw_special_tokens& t = ctx->tok;
-    if (ctx->hp.n_vocab < 51865) throw Error(OHW_E_INVALID_ARG, "language detection needs a multilingual model");
-    const int V = ctx->hp.n_vocab, nl = t.n_langs;
-    std::vector<int32_t> toks((size_t)batch, t.sot), past((size_t)batch, 0);
-    std::vector<float> logits((size_t)batch * V);
-    const int rc = ohw_decode(st, toks.data(), 1, past.data(), batch, logits.data());
-    if (rc != OHW_OK) throw Error(rc, g_last_error);
-    for (int b = 0; b < batch; ++b) {
-      const float* lg = logits.data() + (size_t)b * V + t.sot + 1;
-      float mx = -INFINITY;
-      int best = 0;
-      for (int i = 0; i < nl; ++i) if (lg[i] > mx) { mx = lg[i]; best = i; }
-      lang_ids_out[b] = best;
-      if (lang_probs_out) {
-        double sum = 0.0;
-        for (int i = 0; i < nl; ++i) sum += std::exp((double)(lg[i] - mx));
-        for (int i = 0; i < nl; ++i) lang_probs_out[(size_t)b * nl + i] = (float)(std::exp((double)(lg[i] - mx)) / sum);
-      }
-    }
-  });
-}
-
-int ohw_engine_new(const char* model_path, const char* language, int translate, int use_gpu, int device, int dtype, int max_batch,
-                   ohw_engine** out) {
-  return guard([&] {
-    if (!out) throw Error(OHW_E_INVALID_ARG, "out is null");
-    *out = nullptr;
-    struct stat sb;
-    if (!model_path || stat(model_path, &sb) != 0) {
-      // reference :141-154: the model name is the file stem without "ggml-"
-      std::string stem = model_path ? model_path : "";
-      const size_t slash = stem.find_last_of('/');
-      if (slash != std::string::npos) stem = stem.substr(slash + 1);
-      const size_t dot = stem.find_last_of('.');
-      if (dot != std::string::npos) stem = stem.substr(0, dot);
-      std::string name = stem.rfind("ggml-", 0) == 0 ? stem.substr(5) : "unknown";
-      throw Error(OHW_E_MODEL_NOT_FOUND, std::string("Model not found at ") + (model_path ? model_path : "(null)") +
-                                             ". Run 'openhush model download " + name + "'");
-    }
-    if (!use_gpu)
-      throw Error(OHW_E_NO_GPU, "device = \"cpu\": this engine has no CPU path (set [transcription] device to \"hip:N\")");
-    const std::string lang = language ? language : "auto";
-    if (lang != "auto" && ohw_lang_code_to_id(lang.c_str()) < 0)
-      throw Error(OHW_E_LOAD_FAILED, "unknown language code '" + lang + "'");
-    std::unique_ptr<ohw_engine> e(new ohw_engine());
-    e->language = lang;
-    e->translate = translate != 0;
-    e->max_batch = std::max(1, max_batch);
-    e->device = device;
-    if (const char* ev = getenv("OHW_ENGINE_ENC_CUS")) e->enc_cus = std::max(0, atoi(ev));
-    int rc = ohw_ctx_create(model_path, device, dtype, &e->ctx);
-    if (rc != OHW_OK) throw Error(rc == OHW_E_MODEL_NOT_FOUND ? rc : (rc == OHW_E_NO_GPU || rc == OHW_E_OOM ? rc : OHW_E_LOAD_FAILED),
-                                  "Failed to load model: " + g_last_error);
-    rc = ohw_state_create(e->ctx, e->max_batch, &e->state);
-    if (rc != OHW_OK) {
-      const std::string msg = g_last_error;
-      ohw_ctx_free(e->ctx);
-      e->ctx = nullptr;
-      throw Error(rc == OHW_E_OOM ? rc : OHW_E_LOAD_FAILED, "Failed to create state: " + msg);
-    }
-    *out = e.release();
-  });
-}
-
-void ohw_engine_free(ohw_engine* e) {
-  if (!e) return;
-  ohw_state_free(e->state);
-  if (e->state2) ohw_state_free(e->state2);
-  for (void* st : {e->s_full, e->s_enc, e->s_dec}) if (st) (void)ohw_stream_destroy(st);
-  ohw_ctx_free(e->ctx);
-  delete e;
-}
-
-ohw_state* ohw_engine_state(ohw_engine* e) { return e ? e->state : nullptr; }
-ohw_ctx* ohw_engine_ctx(ohw_engine* e) { return e ? e->ctx : nullptr; }
-
-int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32_t sample_rate, char* text_buf, size_t text_cap,
-                          char* language_out, uint64_t* duration_ms, ohw_audio_info* info_out) {
-  return guard([&] {
-    if (!e) throw Error(OHW_E_INVALID_ARG, "engine is null");
-    ohw_audio_info info;
-    const int vrc = ohw_validate_audio(samples, n, sample_rate, &info);   // reference :206
-    if (info_out) *info_out = info;
-    if (vrc != OHW_OK) {
-      static const char* const names[] = {"ok", "Audio is empty (no samples)", "Unexpected sample rate", "Audio too long", "Audio too short",
-                                          "Audio contains NaN values", "Audio contains infinite values"};
-      throw Error(OHW_E_VALIDATION, std::string("Audio validation failed: ") + names[info.error]);
-    }
-    const auto t0 = std::chrono::steady_clock::now();                       // reference :231
+void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std::string* text_out) {
+  std::string& text = *text_out;
     ohw_sample_params sp;
     ohw_default_sample_params(e->ctx, &sp);
     // reference :246-248: "auto" skips set_language and whisper.cpp keeps its default "en"
@@ -404,7 +177,6 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
     e->last_tokens.clear();
     e->last_quality.clear();
     e->last_trace.clear();
-    std::string text;
     const int max_tok = e->ctx->hp.n_text_ctx;
     const int V = e->ctx->hp.n_vocab;
     const int n_max = sp.n_max;
@@ -621,6 +393,233 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
         restore();
       }
     }
+}
+
+}  // namespace ohw
+
+extern "C" {
+
+const char* ohw_lang_id_to_code(int32_t id) { return (id >= 0 && id < 99) ? kLangs[id] : "unknown"; }
+
+int32_t ohw_lang_code_to_id(const char* code) {
+  if (!code) return -1;
+  for (int i = 0; i < 99; ++i)
+    if (std::strcmp(code, kLangs[i]) == 0) return i;
+  return -1;
+}
+
+int ohw_validate_audio(const float* samples, int64_t n, uint32_t sample_rate, ohw_audio_info* info) {
+  if (!info) return OHW_E_INVALID_ARG;
+  std::memset(info, 0, sizeof *info);
+  auto fail = [&](int code) { info->error = code; return OHW_E_VALIDATION; };
+  if (n <= 0 || !samples) return fail(OHW_AUDIO_EMPTY);                      // validation.rs:51-53
+  if (sample_rate != 16000u) return fail(OHW_AUDIO_BAD_RATE);               // :56-61
+  const float duration = (float)n / (float)sample_rate;                     // :64
+  info->duration_secs = duration;
+  info->sample_count = n;
+  if (duration > 7200.0f) return fail(OHW_AUDIO_TOO_LONG);                  // :67-72 (before the scan)
+  if (duration < 0.1f) return fail(OHW_AUDIO_TOO_SHORT);                    // :74-79
+  float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+  double ss = 0.0;
+  int64_t n_nan = 0, n_inf = 0;
+  for (int64_t i = 0; i < n; ++i) {                                         // :88-98
+    const float v = samples[i];
+    if (std::isnan(v)) ++n_nan;
+    else if (std::isinf(v)) ++n_inf;
+    else { mn = std::min(mn, v); mx = std::max(mx, v); ss += (double)v * (double)v; }
+  }
+  info->nan_count = n_nan;
+  info->inf_count = n_inf;
+  if (n_nan > 0) return fail(OHW_AUDIO_NAN);                                // :100-102
+  if (n_inf > 0) return fail(OHW_AUDIO_INF);                                // :104-106
+  info->min_value = mn;
+  info->max_value = mx;
+  info->rms = (float)std::sqrt(ss / (double)n);                             // :109
+  info->error = OHW_AUDIO_OK;
+  return OHW_OK;
+}
+
+// Host-side logits filter: whisper.cpp's whisper_process_logits with the defaults the reference inherits
+// (SURVEY.md A4.6, Appendix A).  Same rule order as the device sampler in decode.hip.  Masks `logits` in place
+// (timestamp-mass rule included) and returns the log-sum-exp taken BEFORE that rule, as whisper.cpp's logprobs are.
+static float filter_logits(const ohw_ctx* ctx, const ohw_sample_params* p, float* logits, const int32_t* cur, int n_cur) {
+  const ohw_special_tokens& t = ctx->tok;
+  const int V = ctx->hp.n_vocab;
+  const float NEG = -INFINITY;
+  const bool is_initial = n_cur == 0;
+  if (p->suppress_blank && is_initial) {
+    logits[t.eot] = NEG;
+    if (t.blank >= 0) logits[t.blank] = NEG;
+  }
+  logits[t.no_timestamps] = NEG;
+  logits[t.sot] = NEG; logits[t.nosp] = NEG; logits[t.translate] = NEG; logits[t.transcribe] = NEG;
+  logits[t.prev] = NEG; logits[t.solm] = NEG;
+  for (int i = 0; i < t.n_langs; ++i) logits[t.sot + 1 + i] = NEG;
+  if (p->force_len > 0 && n_cur < p->force_len) logits[t.eot] = NEG;
+  if (p->no_timestamps) {
+    for (int i = t.timestamp_begin; i < V; ++i) logits[i] = NEG;
+  } else {
+    const bool last_ts = n_cur > 0 && cur[n_cur - 1] >= t.timestamp_begin;
+    const bool penult_ts = n_cur < 2 || cur[n_cur - 2] >= t.timestamp_begin;
+    if (last_ts) {
+      if (penult_ts) { for (int i = t.timestamp_begin; i < V; ++i) logits[i] = NEG; }
+      else { for (int i = 0; i < t.eot; ++i) logits[i] = NEG; }
+    }
+    if (is_initial && p->max_initial_ts > 0)
+      for (int i = t.timestamp_begin + p->max_initial_ts + 1; i < V; ++i) logits[i] = NEG;
+    int last_seen = -1;
+    for (int i = n_cur - 1; i >= 0; --i) if (cur[i] >= t.timestamp_begin) { last_seen = cur[i]; break; }
+    if (last_seen >= 0) for (int i = t.timestamp_begin; i < last_seen; ++i) logits[i] = NEG;
+  }
+  float mx = NEG;
+  for (int i = 0; i < V; ++i) mx = std::max(mx, logits[i]);
+  double sum = 0.0, ts_sum = 0.0;
+  float text_max = NEG;
+  for (int i = 0; i < V; ++i) {
+    if (!(logits[i] > NEG)) continue;
+    const double e = std::exp((double)(logits[i] - mx));
+    sum += e;
+    if (i >= t.timestamp_begin) ts_sum += e; else text_max = std::max(text_max, logits[i]);
+  }
+  const float lse = mx + (float)std::log(sum);
+  if (!p->no_timestamps && ts_sum > 0.0) {
+    const float ts_lp = mx + (float)std::log(ts_sum) - lse;
+    if (ts_lp > text_max - lse) for (int i = 0; i < t.timestamp_begin; ++i) logits[i] = NEG;
+  }
+  return lse;
+}
+
+int32_t ohw_sample_greedy_host(const ohw_ctx* ctx, const ohw_sample_params* p, float* logits, const int32_t* cur, int n_cur,
+                               float* logprob_out) {
+  if (!ctx || !p || !logits) return -1;
+  const float lse = filter_logits(ctx, p, logits, cur, n_cur);
+  const int V = ctx->hp.n_vocab;
+  int best = 0;
+  float bv = -INFINITY;
+  for (int i = 0; i < V; ++i) if (logits[i] > bv) { bv = logits[i]; best = i; }
+  if (logprob_out) *logprob_out = bv - lse;
+  return best;
+}
+
+// whisper.cpp's decoders draw with std::mt19937 (seeded 0 once per whisper_full call) through
+// std::discrete_distribution over exp(logprobs): whisper_sample_token with best = false (SURVEY.md Appendix A)
+struct ohw_rng { std::mt19937 gen; };
+ohw_rng* ohw_rng_new(uint32_t seed) { return new (std::nothrow) ohw_rng{std::mt19937(seed)}; }
+void ohw_rng_free(ohw_rng* r) { delete r; }
+
+int32_t ohw_sample_host(const ohw_ctx* ctx, const ohw_sample_params* p, float* logits, const int32_t* cur, int n_cur, float temperature,
+                        ohw_rng* rng, float* logprob_out, float* no_speech_prob_out) {
+  if (!ctx || !p || !logits) return -1;
+  const int V = ctx->hp.n_vocab;
+  if (temperature > 0.0f) for (int i = 0; i < V; ++i) logits[i] /= temperature;
+  if (no_speech_prob_out && n_cur == 0) {
+    float mx = -INFINITY;
+    for (int i = 0; i < V; ++i) mx = std::max(mx, logits[i]);
+    double sum = 0.0;
+    for (int i = 0; i < V; ++i) sum += std::exp((double)(logits[i] - mx));
+    *no_speech_prob_out = (float)std::exp((double)(logits[ctx->tok.nosp] - mx) - std::log(sum));
+  }
+  if (!(temperature > 0.0f)) return ohw_sample_greedy_host(ctx, p, logits, cur, n_cur, logprob_out);
+  if (!rng) return -1;
+  const float lse = filter_logits(ctx, p, logits, cur, n_cur);
+  std::vector<float> probs((size_t)V);
+  for (int i = 0; i < V; ++i) probs[(size_t)i] = logits[i] > -INFINITY ? std::exp(logits[i] - lse) : 0.0f;
+  std::discrete_distribution<> dist(probs.begin(), probs.end());
+  const int id = dist(rng->gen);
+  if (logprob_out) *logprob_out = logits[id] - lse;
+  return id;
+}
+
+int ohw_detect_language(ohw_state* st, int batch, int32_t* lang_ids_out, float* lang_probs_out) {
+  return guard([&] {
+    if (!st || !lang_ids_out || batch < 1) throw Error(OHW_E_INVALID_ARG, "bad argument");
+    const ohw_ctx* ctx = ohw_state_ctx(st);
+    const ohw_special_tokens& t = ctx->tok;
+    if (ctx->hp.n_vocab < 51865) throw Error(OHW_E_INVALID_ARG, "language detection needs a multilingual model");
+    const int V = ctx->hp.n_vocab, nl = t.n_langs;
+    std::vector<int32_t> toks((size_t)batch, t.sot), past((size_t)batch, 0);
+    std::vector<float> logits((size_t)batch * V);
+    const int rc = ohw_decode(st, toks.data(), 1, past.data(), batch, logits.data());
+    if (rc != OHW_OK) throw Error(rc, g_last_error);
+    for (int b = 0; b < batch; ++b) {
+      const float* lg = logits.data() + (size_t)b * V + t.sot + 1;
+      float mx = -INFINITY;
+      int best = 0;
+      for (int i = 0; i < nl; ++i) if (lg[i] > mx) { mx = lg[i]; best = i; }
+      lang_ids_out[b] = best;
+      if (lang_probs_out) {
+        double sum = 0.0;
+        for (int i = 0; i < nl; ++i) sum += std::exp((double)(lg[i] - mx));
+        for (int i = 0; i < nl; ++i) lang_probs_out[(size_t)b * nl + i] = (float)(std::exp((double)(lg[i] - mx)) / sum);
+      }
+    }
+  });
+}
+
+int ohw_engine_new(const char* model_path, const char* language, int translate, int use_gpu, int device, int dtype, int max_batch,
+                   ohw_engine** out) {
+  return guard([&] {
+    if (!out) throw Error(OHW_E_INVALID_ARG, "out is null");
+    *out = nullptr;
+    struct stat sb;
+    if (!model_path || stat(model_path, &sb) != 0) {
+      // reference :141-154: the model name is the file stem without "ggml-"
+      std::string stem = model_path ? model_path : "";
+      const size_t slash = stem.find_last_of('/');
+      if (slash != std::string::npos) stem = stem.substr(slash + 1);
+      const size_t dot = stem.find_last_of('.');
+      if (dot != std::string::npos) stem = stem.substr(0, dot);
+      std::string name = stem.rfind("ggml-", 0) == 0 ? stem.substr(5) : "unknown";
+      throw Error(OHW_E_MODEL_NOT_FOUND, std::string("Model not found at ") + (model_path ? model_path : "(null)") +
+                                             ". Run 'openhush model download " + name + "'");
+    }
+    if (!use_gpu)
+      throw Error(OHW_E_NO_GPU, "device = \"cpu\": this engine has no CPU path (set [transcription] device to \"hip:N\")");
+    const std::string lang = language ? language : "auto";
+    if (lang != "auto" && ohw_lang_code_to_id(lang.c_str()) < 0)
+      throw Error(OHW_E_LOAD_FAILED, "unknown language code '" + lang + "'");
+    ohw_ctx* ctx = nullptr;
+    int rc = ohw_ctx_create(model_path, device, dtype, &ctx);
+    if (rc != OHW_OK) throw Error(rc == OHW_E_MODEL_NOT_FOUND ? rc : (rc == OHW_E_NO_GPU || rc == OHW_E_OOM ? rc : OHW_E_LOAD_FAILED),
+                                  "Failed to load model: " + g_last_error);
+    std::unique_ptr<ohw_engine> e;
+    try {
+      e.reset(engine_wrap_ctx(ctx, lang, translate != 0, max_batch, device));
+    } catch (...) {
+      ohw_ctx_free(ctx);
+      throw;
+    }
+    *out = e.release();
+  });
+}
+
+void ohw_engine_free(ohw_engine* e) {
+  if (!e) return;
+  ohw_state_free(e->state);
+  if (e->state2) ohw_state_free(e->state2);
+  for (void* st : {e->s_full, e->s_enc, e->s_dec}) if (st) (void)ohw_stream_destroy(st);
+  ohw_ctx_free(e->ctx);
+  delete e;
+}
+
+ohw_state* ohw_engine_state(ohw_engine* e) { return e ? e->state : nullptr; }
+ohw_ctx* ohw_engine_ctx(ohw_engine* e) { return e ? e->ctx : nullptr; }
+
+int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32_t sample_rate, char* text_buf, size_t text_cap,
+                          char* language_out, uint64_t* duration_ms, ohw_audio_info* info_out) {
+  return guard([&] {
+    if (!e) throw Error(OHW_E_INVALID_ARG, "engine is null");
+    ohw_audio_info info;
+    const int vrc = ohw_validate_audio(samples, n, sample_rate, &info);   // reference :206
+    if (info_out) *info_out = info;
+    if (vrc != OHW_OK) {
+      static const char* const names[] = {"ok", "Audio is empty (no samples)", "Unexpected sample rate", "Audio too long", "Audio too short",
+                                          "Audio contains NaN values", "Audio contains infinite values"};
+      throw Error(OHW_E_VALIDATION, std::string("Audio validation failed: ") + names[info.error]);
+    }
+    const auto t0 = std::chrono::steady_clock::now();                       // reference :231
+    std::string text;
+    engine_transcribe_core(e, samples, n, &text);
     // reference :282-283: trim
     const size_t b0 = text.find_first_not_of(" \t\r\n");
     const size_t b1 = text.find_last_not_of(" \t\r\n");
@@ -633,7 +632,7 @@ int ohw_engine_transcribe(ohw_engine* e, const float* samples, int64_t n, uint32
     }
     if (language_out) {
       // reference :288-296: "auto" reports the state's language id (whisper.cpp default "en" -> 0)
-      const std::string lang = e->language == "auto" ? ohw_lang_id_to_code(sp.lang_id) : e->language;
+      const std::string lang = e->language == "auto" ? ohw_lang_id_to_code(0) : e->language;
       std::strncpy(language_out, lang.c_str(), 7);
       language_out[7] = 0;
     }

@@ -1,0 +1,34 @@
+// host_engine.hpp — the engine object behind ohw_engine_* (host_engine.cpp) and the multi-device pool (pool.cpp).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+struct ohw_engine {
+  ohw_ctx* ctx = nullptr;
+  ohw_state* state = nullptr;
+  std::string language;
+  bool translate = false;
+  int max_batch = 1;
+  int window_mode = OHW_WINDOW_FIXED;
+  std::vector<int32_t> last_tokens;
+  std::string last_text;
+  std::vector<ohw_window_quality> last_quality;
+  // two batches in flight for audio longer than max_batch windows (include/ohw.h, ohw_stream_create): a second state
+  // and three streams, made on first use; enc_cus = 0 keeps the batches strictly one after the other
+  ohw_state* state2 = nullptr;
+  void* s_full = nullptr; void* s_enc = nullptr; void* s_dec = nullptr;
+  int enc_cus = 96;
+  int device = 0;
+  ohw_decode_policy policy{0.2f, 2.4f, -1.0f, 0.6f};
+  std::vector<int32_t> last_trace;   // every decode pass of the last transcribe: {window, temperature * 1000, n, tokens...}
+};
+
+
+namespace ohw {
+// an engine around an already loaded context (takes ownership of ctx on success); throws Error
+ohw_engine* engine_wrap_ctx(ohw_ctx* ctx, const std::string& language, bool translate, int max_batch, int device);
+// the path after validation: windows, decode policy, text assembly (untrimmed text in *text); fills the engine's last_* records
+void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std::string* text);
+}  // namespace ohw

@@ -101,6 +101,8 @@ EXPORTS = [
     "ohw_greedy_ex", "ohw_state_set_logit_bias", "ohw_dbg_sample",
     "ohw_decode_active", "ohw_rng_new", "ohw_rng_free", "ohw_sample_host", "ohw_default_decode_policy", "ohw_engine_set_decode_policy",
     "ohw_engine_last_trace",
+    "ohw_pool_create", "ohw_pool_transcribe", "ohw_pool_last_text", "ohw_pool_last_tokens", "ohw_pool_last_quality",
+    "ohw_pool_set_decode_policy", "ohw_pool_n_devices", "ohw_pool_broadcast_kind", "ohw_pool_engine", "ohw_pool_free",
 ]
 
 
@@ -218,6 +220,19 @@ def lib():
         L.ohw_engine_state.restype = vp
         L.ohw_engine_ctx.argtypes = [vp]
         L.ohw_engine_ctx.restype = vp
+        L.ohw_pool_create.argtypes = [C.c_char_p, C.c_char_p, C.c_int, ip, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        L.ohw_pool_transcribe.argtypes = [vp, fp, C.c_int64, C.c_uint32, C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(AudioInfo)]
+        L.ohw_pool_last_text.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+        L.ohw_pool_last_tokens.argtypes = [vp, C.POINTER(ip), C.POINTER(C.c_int)]
+        L.ohw_pool_last_quality.argtypes = [vp, C.POINTER(C.POINTER(WindowQuality)), C.POINTER(C.c_int)]
+        L.ohw_pool_set_decode_policy.argtypes = [vp, C.POINTER(DecodePolicy)]
+        L.ohw_pool_n_devices.argtypes = [vp]
+        L.ohw_pool_broadcast_kind.argtypes = [vp]
+        L.ohw_pool_broadcast_kind.restype = C.c_char_p
+        L.ohw_pool_engine.argtypes = [vp, C.c_int]
+        L.ohw_pool_engine.restype = vp
+        L.ohw_pool_free.argtypes = [vp]
+        L.ohw_pool_free.restype = None
         L.ohw_state_fetch.argtypes = [vp, C.c_char_p, C.c_int, fp, C.c_int64]
         L.ohw_state_profile_begin.argtypes = [vp, C.c_int]
         L.ohw_state_profile_end.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -750,6 +765,68 @@ class WhisperEngine:
     def close(self):
         if getattr(self, "h", None):
             lib().ohw_engine_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class EnginePool:
+    """ohw_pool: one engine per device of one node behind the C ABI (the reference's `[gpu] devices` intent,
+    src/config.rs:921-929).  transcribe() has WhisperEngine.transcribe's contract."""
+
+    def __init__(self, model_path: str, language: str = "auto", translate: bool = False, devices: Sequence[int] = (0,),
+                 dtype: int = OHW_DTYPE_BF16, max_batch: int = 1):
+        ids = np.asarray(list(devices), dtype=np.int32)
+        h = C.c_void_p()
+        rc = lib().ohw_pool_create(str(model_path).encode(), language.encode(), int(translate), _ip(ids), len(ids), dtype, max_batch, C.byref(h))
+        if rc != 0:
+            _raise(rc)
+        self.h = h
+
+    @property
+    def n_devices(self) -> int:
+        return int(lib().ohw_pool_n_devices(self.h))
+
+    @property
+    def broadcast_kind(self) -> str:
+        return lib().ohw_pool_broadcast_kind(self.h).decode()
+
+    def set_decode_policy(self, **kw):
+        pol = DecodePolicy()
+        lib().ohw_default_decode_policy(C.byref(pol))
+        for k, v in kw.items():
+            setattr(pol, k, v)
+        _check(lib().ohw_pool_set_decode_policy(self.h, C.byref(pol)))
+
+    def transcribe(self, audio: AudioBuffer) -> TranscriptionResult:
+        s = np.ascontiguousarray(audio.samples, dtype=np.float32)
+        buf, lang, ms, info = C.create_string_buffer(256), C.create_string_buffer(8), C.c_uint64(0), AudioInfo()
+        ptr = _fp(s) if s.size else C.cast(None, C.POINTER(C.c_float))
+        rc = lib().ohw_pool_transcribe(self.h, ptr, s.size, audio.sample_rate, buf, len(buf), lang, C.byref(ms), C.byref(info))
+        if rc != 0:
+            _raise(rc, info)
+        full, n = C.c_char_p(), C.c_size_t(0)
+        _check(lib().ohw_pool_last_text(self.h, C.byref(full), C.byref(n)))
+        text = C.string_at(full, n.value).decode("utf-8", "replace") if n.value else ""
+        return TranscriptionResult(text, lang.value.decode(), int(ms.value))
+
+    def last_tokens(self) -> List[int]:
+        p, n = C.POINTER(C.c_int32)(), C.c_int(0)
+        _check(lib().ohw_pool_last_tokens(self.h, C.byref(p), C.byref(n)))
+        return [int(p[i]) for i in range(n.value)]
+
+    def last_window_tokens(self) -> List[int]:
+        q, n = C.POINTER(WindowQuality)(), C.c_int(0)
+        _check(lib().ohw_pool_last_quality(self.h, C.byref(q), C.byref(n)))
+        return [int(q[i].n_tokens) for i in range(n.value)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ohw_pool_free(self.h)
             self.h = None
 
     def __del__(self):

@@ -201,6 +201,8 @@ def test_split_k_residual_gemms_match_unsplit(E, models, monkeypatch):
     pcm, ns = _pcm_batch()
     toks = np.tile(np.array([ctx.tok.sot, ctx.tok.sot + 1, ctx.tok.transcribe, 60, 70, 80], np.int32), (3, 1))
 
+    monkeypatch.setenv("OHW_DEC_POSTNORM", "0")       # the split path publishes no tile statistics: compare like with like
+
     def logits(long, short):
         monkeypatch.setenv("OHW_DEC_KSPLIT_LONG", str(long))
         monkeypatch.setenv("OHW_DEC_KSPLIT_SHORT", str(short))

@@ -19,7 +19,7 @@ a = ap.parse_args()
 hp = synth.PRESETS["large-v3"]
 ctx = E.Context.synthetic(hp.as_list(), 1234, 0, E.OHW_DTYPE_BF16)
 B = a.batch
-NMAX = 4
+NMAX = 8
 sts = [E.State(ctx, B) for _ in range(NMAX)]
 pcm = torch.from_numpy(np.stack([synth.synth_audio(b) for b in range(B)])).cuda()
 p = ctx.default_params(); p.force_len = a.tokens
@@ -53,8 +53,9 @@ def side_by_side(n):
 
 t1 = timed(lambda: one(sts[0]))
 print(f"one decode of {B} windows, {a.tokens} tokens, all CUs:      {t1:7.1f} ms", flush=True)
-for n, splits in ((2, [(0, 128), (128, 128)]), (2, [(0, 144), (112, 144)]), (2, [(0, 160), (96, 160)]), (2, [(0, 192), (64, 192)]),
-                  (3, [(0, 85), (85, 85), (170, 86)]), (3, [(0, 128), (64, 128), (128, 128)]), (4, [(0, 64), (64, 64), (128, 64), (192, 64)])):
+for n, splits in ((4, [(0, 64), (64, 64), (128, 64), (192, 64)]), (4, [(0, 128), (43, 128), (85, 128), (128, 128)]),
+                  (4, [(0, 256), (0, 256), (0, 256), (0, 256)]), (6, [(i * 42, 42) for i in range(6)]), (8, [(i * 32, 32) for i in range(8)]),
+                  (8, [(i * 32 - (32 if i else 0), 64) for i in range(8)])):
     ms = [E.Stream(0, f, c) for f, c in splits]
     for s, f in zip(sts, ms):
         s.set_stream(f.ptr)
