@@ -38,8 +38,8 @@ PROF_NAMES = {1: "gemm256_kernel (encoder / cross-KV MFMA GEMM)", 2: "encoder_at
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--tokens", type=int, default=100)
@@ -47,14 +47,15 @@ def main():
     ap.add_argument("--profile-class", type=int, default=0, help="0 = pick the class with the largest total time")
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many concurrent states/streams")
     ap.add_argument("--pipeline", type=int, default=96,
-                    help="N > 0 (default 96): two batches in flight - mel/encoder/cross-K/V of batch i+1 on N compute units beside the "
-                         "decoder of batch i on the rest; 0: one batch after the other")
+                    help="with --phases 0 or 1: N > 0 puts two batches in flight - mel/encoder/cross-K/V of batch i+1 on N compute units "
+                         "beside the decoder of batch i on the rest (round 1's schedule); 0: one batch after the other")
     ap.add_argument("--decoders", type=int, default=1,
                     help="with --pipeline: decodes in flight beside the front end (each on its own CU-masked stream, driven by its own "
                          "host thread): the latency-bound GEMM chain of one decode hides under the K/V stream of the other")
-    ap.add_argument("--phases", type=int, default=0,
-                    help="G > 1: no front-end / decode overlap; the front ends of G batches run one after the other on every CU, then "
-                         "their G decodes side by side on G disjoint CU sets (one's latency-bound GEMM chain under the others' K/V streams)")
+    ap.add_argument("--phases", type=int, default=4,
+                    help="G > 1 (default 4, the engine's LANES schedule): the front ends of G batches run one after the other on every CU, "
+                         "then their G decodes side by side on G disjoint CU sets (one's latency-bound GEMM chain under the others' K/V "
+                         "streams); 0 or 1: see --pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=0, help="decode tokens in the CPU sample (0 = same as --tokens)")
     ap.add_argument("--cpu-windows", type=int, default=2, help="30 s windows in the CPU sample")

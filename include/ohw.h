@@ -284,6 +284,18 @@ int ohw_engine_last_trace(ohw_engine* e, const int32_t** data, int* n);
  * stops when less than 1 s is left.  One window at a time, so batch = 1. */
 enum { OHW_WINDOW_FIXED = 0, OHW_WINDOW_SEEK = 1 };
 int ohw_engine_set_window_mode(ohw_engine* e, int mode);
+/* How audio of more than max_batch windows is overlapped on the device (the reference transcribes one buffer at a time,
+ * src/queue/worker.rs:100-160; results are identical under every schedule):
+ *   SEQUENTIAL  one batch after the other;
+ *   PIPELINE    front end (mel, encoder, cross K/V) of batch i+1 on OHW_ENGINE_ENC_CUS compute units beside the decode of
+ *               batch i on the rest (round 1's schedule);
+ *   LANES       (default) groups of `lanes` batches: their front ends one after the other on every compute unit, then
+ *               their decodes side by side, each on its own CU-masked stream and host thread - a decode alternates an
+ *               HBM-bound kernel with a latency-bound chain, several of them together keep HBM busy.
+ * The schedule's extra states and streams are made when a long input first needs them; environment defaults:
+ * OHW_ENGINE_SCHEDULE = sequential | pipeline | lanes, OHW_ENGINE_LANES (4), OHW_ENGINE_ENC_CUS (96). */
+enum { OHW_SCHEDULE_SEQUENTIAL = 0, OHW_SCHEDULE_PIPELINE = 1, OHW_SCHEDULE_LANES = 2 };
+int ohw_engine_set_schedule(ohw_engine* e, int schedule, int lanes /* 0 = keep */);
 /* tokens of the last transcribe, per 30 s window concatenated (for parity tests)                  */
 int ohw_engine_last_tokens(ohw_engine* e, const int32_t** tokens, int* n);
 /* WhisperEngine::benchmark(safety_margin) — reference :334-387                                    */

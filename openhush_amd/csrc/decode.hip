@@ -562,11 +562,13 @@ static void dec_gemm_pick(const DecGemmParams& p, hipStream_t s) {
     if (msplit && p.ksplit <= 1 && (mt == 1 || n_tiles * mt <= 2 * cus)) { dec_gemm_launch<T, EPI, LN, 1, 1>(p, s); return; }
   }
   if constexpr (!LN && (EPI == DEPI_QKV || EPI == DEPI_BIAS_T || EPI == DEPI_BIAS_GELU_T)) {
-    // post-norm consumers carry no LDS image: two workgroups share a CU, so the grid may be two waves of CUs
-    if (msplit && mt <= 2) {
-      if (n_tiles * mt <= 2 * cus) { dec_gemm_launch<T, EPI, LN, 1, 1>(p, s); return; }
-      if ((n_tiles + 1) / 2 * mt <= 2 * cus || mt == 1) { dec_gemm_launch<T, EPI, LN, 2, 1>(p, s); return; }
+    // post-norm consumers: the same grid rule as the LayerNorm variants (one workgroup per CU: at 512 threads and up to
+    // 256 registers a second workgroup does not fit beside it; a two-round grid doubled the QKV launch, 4.9 -> 8.9 us)
+    if (p.pn && msplit && mt <= 2) {
+      if (n_tiles * mt <= cus) { dec_gemm_launch<T, EPI, LN, 1, 1>(p, s); return; }
+      if ((n_tiles + 1) / 2 * mt <= cus || mt == 1) { dec_gemm_launch<T, EPI, LN, 2, 1>(p, s); return; }
     }
+    if (p.pn && n_tiles > cus) { dec_gemm_launch<T, EPI, LN, 2, 2>(p, s); return; }
   }
   if constexpr (LN) {
     // one m-tile per workgroup halves the fp32 rows a workgroup normalises; pick the n-tiles per workgroup that keep

@@ -176,9 +176,10 @@ void state_alloc(ohw_state* st) {
   // multiplied but never stored)
   const size_t m_tiles = ((size_t)st->m_max + 31) / 32 * 32;
   st->dy.alloc(m_tiles * dt * 2, true);
-  // post-norm decoder GEMMs (decode.hip): on unless OHW_DEC_POSTNORM=0 or a split-K knob is set (the split path publishes
-  // no statistics); dt must be a multiple of 32
-  st->postnorm = env_int("OHW_DEC_POSTNORM", 1, 0, 1) != 0 && dec_ksplit_long() == 1 && dec_ksplit_short() == 1 && dt % 32 == 0;
+  // post-norm decoder GEMMs (decode.hip): OHW_DEC_POSTNORM=1 (off by default: measured, no gain - the LayerNorm prologue
+  // already hides under the weights' first-byte latency); never with a split-K knob (the split path
+  // publishes no statistics); dt must be a multiple of 32
+  st->postnorm = env_int("OHW_DEC_POSTNORM", 0, 0, 1) != 0 && dec_ksplit_long() == 1 && dec_ksplit_short() == 1 && dt % 32 == 0;
   st->dx16.alloc(m_tiles * dt * 2, true);
   st->xstat.alloc((size_t)st->m_max * (dt / 16) * 2 * 4, true);
   st->dq.alloc((size_t)st->m_max * dt * 2);

@@ -156,6 +156,11 @@ ohw_engine* engine_wrap_ctx(ohw_ctx* ctx, const std::string& language, bool tran
   e->max_batch = std::max(1, max_batch);
   e->device = device;
   if (const char* ev = getenv("OHW_ENGINE_ENC_CUS")) e->enc_cus = std::max(0, atoi(ev));
+  if (const char* ev = getenv("OHW_ENGINE_LANES")) e->lanes = std::min(16, std::max(1, atoi(ev)));
+  if (const char* ev = getenv("OHW_ENGINE_SCHEDULE")) {
+    const std::string v = ev;
+    e->schedule = v == "sequential" ? OHW_SCHEDULE_SEQUENTIAL : v == "pipeline" ? OHW_SCHEDULE_PIPELINE : OHW_SCHEDULE_LANES;
+  }
   const int rc = ohw_state_create(ctx, e->max_batch, &e->state);
   if (rc != OHW_OK) throw Error(rc == OHW_E_OOM ? rc : OHW_E_LOAD_FAILED, "Failed to create state: " + g_last_error);
   e->ctx = ctx;
@@ -188,15 +193,23 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
     if (V >= 51865) { prompt[n_prompt++] = tk.sot + 1 + sp.lang_id; prompt[n_prompt++] = sp.translate ? tk.translate : tk.transcribe; }
     if (sp.no_timestamps) prompt[n_prompt++] = tk.no_timestamps;
     auto check = [&](int rc) { if (rc != OHW_OK) throw Error(OHW_E_TRANSCRIBE, "Transcription failed: " + g_last_error); };   // reference :266-268
-    auto trace = [&](int64_t window, float temp, const std::vector<int32_t>& t) {
-      e->last_trace.push_back((int32_t)window); e->last_trace.push_back((int32_t)std::lround(temp * 1000.f)); e->last_trace.push_back((int32_t)t.size());
-      e->last_trace.insert(e->last_trace.end(), t.begin(), t.end());
+    // per-decode scratch: one per lane when several batches decode side by side
+    struct Scratch {
+      std::vector<int32_t> toks, ntok, eot, trace;
+      std::vector<float> lps, nsp, logits;
+      std::vector<WindowRun> runs;
+      Scratch(int B, int max_tok) : toks((size_t)B * max_tok), ntok((size_t)B), eot((size_t)B), lps((size_t)B * (max_tok + 1)), nsp((size_t)B) {}
+    };
+    auto trace = [&](Scratch& sc, int64_t window, float temp, const std::vector<int32_t>& t) {
+      sc.trace.push_back((int32_t)window); sc.trace.push_back((int32_t)std::lround(temp * 1000.f)); sc.trace.push_back((int32_t)t.size());
+      sc.trace.insert(sc.trace.end(), t.begin(), t.end());
     };
 
     // T = 0: the device-resident greedy loop for B windows; then whisper.cpp's bookkeeping per window
-    std::vector<int32_t> toks((size_t)e->max_batch * max_tok), ntok((size_t)e->max_batch), eot((size_t)e->max_batch);
-    std::vector<float> lps((size_t)e->max_batch * (max_tok + 1)), nsp((size_t)e->max_batch);
-    auto greedy_t0 = [&](ohw_state* st, int B, const int* seek, const int* seek_end, int64_t w0, std::vector<WindowRun>& runs) {
+    auto greedy_t0 = [&](Scratch& sc, ohw_state* st, int B, const int* seek, const int* seek_end, int64_t w0) {
+      std::vector<int32_t>&toks = sc.toks, &ntok = sc.ntok, &eot = sc.eot;
+      std::vector<float>&lps = sc.lps, &nsp = sc.nsp;
+      std::vector<WindowRun>& runs = sc.runs;
       ohw_greedy_result gr{};
       gr.tokens = toks.data(); gr.n_tokens = ntok.data(); gr.token_logprobs = lps.data(); gr.ended_by_eot = eot.data(); gr.no_speech_prob = nsp.data();
       check(ohw_greedy_ex(st, &sp, B, max_tok, &gr));
@@ -211,15 +224,15 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
         r.ev = evaluate_sequence(tk, r.tok.data(), r.plog.data(), nt, seek[b], seek_end[b], n_max, sp.no_timestamps != 0, e->window_mode);
         r.t0_failed = needs_fallback(r.ev, pol, r.nosp, false);
         r.pending = needs_fallback(r.ev, pol, r.nosp, temps.empty());
-        trace(w0 + b, 0.f, r.tok);
+        trace(sc, w0 + b, 0.f, r.tok);
       }
     };
     // the temperature ladder for the windows of a batch whose pass failed the acceptance test: the HOST samples
     // (std::mt19937 + std::discrete_distribution, as whisper.cpp's decoders do), the device runs the decoder steps of the
     // pending windows only and re-uses their resident cross K/V; the logits of the pending rows cross PCIe every step
-    std::vector<float> logits;
-    auto run_ladder = [&](ohw_state* st, int B, const int* seek, const int* seek_end, int64_t w0, std::vector<WindowRun>& runs,
-                          const std::vector<ohw_rng*>& rngs) {
+    auto run_ladder = [&](Scratch& sc, ohw_state* st, int B, const int* seek, const int* seek_end, int64_t w0, const std::vector<ohw_rng*>& rngs) {
+      std::vector<float>& logits = sc.logits;
+      std::vector<WindowRun>& runs = sc.runs;
       for (size_t ti = 0; ti < temps.size(); ++ti) {
         std::vector<int32_t> active((size_t)B, 0);
         bool any = false;
@@ -259,7 +272,7 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
           r.ev = evaluate_sequence(tk, r.tok.data(), r.plog.data(), (int)r.tok.size(), seek[b], seek_end[b], n_max, sp.no_timestamps != 0, e->window_mode);
           r.t0_failed = runs[(size_t)b].t0_failed;
           r.pending = needs_fallback(r.ev, pol, r.nosp, is_last);
-          trace(w0 + b, T, r.tok);
+          trace(sc, w0 + b, T, r.tok);
           runs[(size_t)b] = std::move(r);
         }
       }
@@ -288,23 +301,25 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
       void reset(size_t nr) { for (ohw_rng* r : v) ohw_rng_free(r); v.clear(); for (size_t i = 0; i < nr; ++i) v.push_back(ohw_rng_new(0)); }
     } rngs;
 
+    auto flush_trace = [&](Scratch& sc) { e->last_trace.insert(e->last_trace.end(), sc.trace.begin(), sc.trace.end()); sc.trace.clear(); };
     if (e->window_mode == OHW_WINDOW_SEEK) {
       // whisper.cpp's seek loop as recalled: sequential windows, advanced by the last timestamp; one
       // generator for the whole call
       rngs.reset(1);
+      Scratch sc(1, max_tok);
       const int seek_end = mel_frames(n);
       int seek = 0;
-      std::vector<WindowRun> runs;
       int64_t w = 0;
       while (seek_end >= 100 && seek + 100 < seek_end) {
         const int64_t off = (int64_t)seek * HOP;
         const int32_t ns1 = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - off);
         check(ohw_mel(e->state, samples + off, CHUNK_SAMPLES, &ns1, 1, 0, OHW_MEL_ZERO_TAIL, nullptr));
         check(ohw_encode(e->state, 1));
-        greedy_t0(e->state, 1, &seek, &seek_end, w, runs);
-        run_ladder(e->state, 1, &seek, &seek_end, w, runs, rngs.v);
-        emit(runs[0]);
-        seek += runs[0].ev.seek_delta > 0 ? runs[0].ev.seek_delta : 3000;
+        greedy_t0(sc, e->state, 1, &seek, &seek_end, w);
+        run_ladder(sc, e->state, 1, &seek, &seek_end, w, rngs.v);
+        flush_trace(sc);
+        emit(sc.runs[0]);
+        seek += sc.runs[0].ev.seek_delta > 0 ? sc.runs[0].ev.seek_delta : 3000;
         ++w;
       }
     } else {
@@ -312,66 +327,98 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
       // whisper.cpp terms: seek 0, its own frame count as the end of the audio, a fresh generator - and, like a call with
       // less than 1 s of audio (`seek + 100 >= seek_end` before the first window), a cut of at most 100 frames yields nothing
       const int64_t n_win = (n + CHUNK_SAMPLES - 1) / CHUNK_SAMPLES;
-      std::vector<int32_t> ns((size_t)e->max_batch);
       const int64_t n_batches = (n_win + e->max_batch - 1) / e->max_batch;
       auto batch_of = [&](int64_t bi) { return (int)std::min<int64_t>(e->max_batch, n_win - bi * e->max_batch); };
-      std::vector<int> zero((size_t)e->max_batch, 0), ends((size_t)e->max_batch);
-      std::vector<WindowRun> runs;
-      auto decode_batch = [&](ohw_state* st, int64_t bi, const int32_t* nsb) {
+      auto fill_ns = [&](int64_t bi, std::vector<int32_t>& nsv) {
+        const int64_t w0 = bi * e->max_batch;
         const int B = batch_of(bi);
-        for (int b = 0; b < B; ++b) ends[(size_t)b] = mel_frames(nsb[b]);
-        greedy_t0(st, B, zero.data(), ends.data(), bi * e->max_batch, runs);
-        for (int b = 0; b < B; ++b) if (ends[(size_t)b] <= 100) { runs[(size_t)b] = WindowRun(); runs[(size_t)b].ev.result_len = 0; }
-        bool any = false;
-        for (int b = 0; b < B; ++b) any = any || runs[(size_t)b].pending;
-        if (any) { rngs.reset((size_t)B); run_ladder(st, B, zero.data(), ends.data(), bi * e->max_batch, runs, rngs.v); }
-        for (int b = 0; b < B; ++b) emit(runs[(size_t)b]);
+        for (int b = 0; b < B; ++b) nsv[(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + b) * CHUNK_SAMPLES);
       };
-      bool pipelined = n_batches > 1 && e->enc_cus > 0;
-      if (pipelined && !e->state2) {
-        // first long input: the second state and the three streams (all CUs / encoder's share / decoder's share)
-        int rc = ohw_state_create(e->ctx, e->max_batch, &e->state2);
-        if (rc == OHW_OK) rc = ohw_stream_create(e->device, 0, 0, &e->s_full);
-        int total = 0;
-        if (rc == OHW_OK && hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) rc = OHW_E_TRANSCRIBE;
-        if (rc == OHW_OK && e->enc_cus >= total) e->enc_cus = std::max(1, total * 3 / 8);   // a smaller device: the same 3 : 5 split
-        if (rc == OHW_OK) rc = ohw_stream_create(e->device, 0, e->enc_cus, &e->s_enc);
-        if (rc == OHW_OK) rc = ohw_stream_create(e->device, e->enc_cus, total - e->enc_cus, &e->s_dec);
+      auto front = [&](int64_t bi, ohw_state* st, void* stream, std::vector<int32_t>& nsv) {
+        fill_ns(bi, nsv);
+        check(ohw_state_set_stream(st, stream));
+        check(ohw_mel(st, samples + bi * e->max_batch * CHUNK_SAMPLES, CHUNK_SAMPLES, nsv.data(), batch_of(bi), 0, OHW_MEL_ZERO_TAIL, nullptr));
+        check(ohw_encode(st, batch_of(bi)));
+      };
+      // the decode of one batch on whatever stream the state is set to; fills sc.runs (and sc.trace); re-entrant per Scratch
+      auto decode_batch = [&](Scratch& sc, ohw_state* st, int64_t bi, const int32_t* nsb) {
+        const int B = batch_of(bi);
+        std::vector<int> zero((size_t)B, 0), ends((size_t)B);
+        for (int b = 0; b < B; ++b) ends[(size_t)b] = mel_frames(nsb[b]);
+        greedy_t0(sc, st, B, zero.data(), ends.data(), bi * e->max_batch);
+        for (int b = 0; b < B; ++b) if (ends[(size_t)b] <= 100) { sc.runs[(size_t)b] = WindowRun(); sc.runs[(size_t)b].ev.result_len = 0; }
+        bool any = false;
+        for (int b = 0; b < B; ++b) any = any || sc.runs[(size_t)b].pending;
+        if (any) {
+          Rngs lr;
+          lr.reset((size_t)B);
+          run_ladder(sc, st, B, zero.data(), ends.data(), bi * e->max_batch, lr.v);
+        }
+      };
+      auto collect = [&](Scratch& sc, int B) {
+        flush_trace(sc);
+        for (int b = 0; b < B; ++b) emit(sc.runs[(size_t)b]);
+      };
+      int schedule = n_batches > 1 ? e->schedule : OHW_SCHEDULE_SEQUENTIAL;
+      if (schedule == OHW_SCHEDULE_LANES && e->lanes < 2) schedule = OHW_SCHEDULE_SEQUENTIAL;
+      if (schedule == OHW_SCHEDULE_PIPELINE && e->enc_cus <= 0) schedule = OHW_SCHEDULE_SEQUENTIAL;
+      // ---- resources of the overlapped schedules, made when a long input first needs them: more states, CU-masked streams ----
+      if (schedule != OHW_SCHEDULE_SEQUENTIAL) {
+        int rc = OHW_OK, total = 0;
+        if (hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || total < 2) rc = OHW_E_TRANSCRIBE;
+        if (rc == OHW_OK && !e->s_full) rc = ohw_stream_create(e->device, 0, 0, &e->s_full);
+        if (e->states.empty()) e->states.assign(1, e->state);
+        const int want_states = schedule == OHW_SCHEDULE_LANES ? (int)std::min<int64_t>(e->lanes, n_batches) : 2;
+        while (rc == OHW_OK && (int)e->states.size() < want_states) {
+          ohw_state* st = nullptr;
+          rc = ohw_state_create(e->ctx, e->max_batch, &st);
+          if (rc == OHW_OK) e->states.push_back(st);
+        }
+        if (rc == OHW_OK && schedule == OHW_SCHEDULE_PIPELINE && !e->s_enc) {
+          if (e->enc_cus >= total) e->enc_cus = std::max(1, total * 3 / 8);   // a smaller device: the same 3 : 5 split
+          rc = ohw_stream_create(e->device, 0, e->enc_cus, &e->s_enc);
+          if (rc == OHW_OK) rc = ohw_stream_create(e->device, e->enc_cus, total - e->enc_cus, &e->s_dec);
+        }
+        if (rc == OHW_OK && schedule == OHW_SCHEDULE_LANES && (int)e->lane_streams.size() != want_states) {
+          for (void* ls : e->lane_streams) (void)ohw_stream_destroy(ls);     // another lane count: other CU ranges
+          e->lane_streams.clear();
+          const int per = std::max(1, total / want_states);
+          for (int i = 0; rc == OHW_OK && i < want_states; ++i) {
+            void* ls = nullptr;
+            rc = ohw_stream_create(e->device, i * per, per, &ls);
+            if (rc == OHW_OK) e->lane_streams.push_back(ls);
+          }
+        }
         if (rc != OHW_OK) {
-          // no CU-masked queues (or no memory for the second state) here: one batch after the other from now on
-          if (e->state2) { ohw_state_free(e->state2); e->state2 = nullptr; }
+          // no CU-masked queues (or no memory for more states) here: one batch after the other from now on
+          for (size_t i = 1; i < e->states.size(); ++i) ohw_state_free(e->states[i]);
+          e->states.clear();
+          for (void* ls : e->lane_streams) (void)ohw_stream_destroy(ls);
+          e->lane_streams.clear();
           for (void** st : {&e->s_full, &e->s_enc, &e->s_dec}) if (*st) { (void)ohw_stream_destroy(*st); *st = nullptr; }
-          e->enc_cus = 0;
-          pipelined = false;
+          e->schedule = schedule = OHW_SCHEDULE_SEQUENTIAL;
         }
       }
-      if (!pipelined) {
+      if (schedule == OHW_SCHEDULE_LANES && (int)e->lane_streams.size() < 2) schedule = OHW_SCHEDULE_SEQUENTIAL;
+      if (schedule == OHW_SCHEDULE_PIPELINE && (e->states.size() < 2 || !e->s_enc)) schedule = OHW_SCHEDULE_SEQUENTIAL;
+      auto restore = [&] { for (ohw_state* st : e->states) (void)ohw_state_set_stream(st, nullptr); (void)ohw_state_set_stream(e->state, nullptr); };
+      if (schedule == OHW_SCHEDULE_SEQUENTIAL) {
+        Scratch sc(e->max_batch, max_tok);
+        std::vector<int32_t> ns((size_t)e->max_batch);
         for (int64_t bi = 0; bi < n_batches; ++bi) {
-          const int64_t w0 = bi * e->max_batch;
-          const int B = batch_of(bi);
-          for (int b = 0; b < B; ++b) ns[(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + b) * CHUNK_SAMPLES);
-          check(ohw_mel(e->state, samples + w0 * CHUNK_SAMPLES, CHUNK_SAMPLES, ns.data(), B, 0, OHW_MEL_ZERO_TAIL, nullptr));
-          check(ohw_encode(e->state, B));
-          decode_batch(e->state, bi, ns.data());
+          fill_ns(bi, ns);
+          check(ohw_mel(e->state, samples + bi * e->max_batch * CHUNK_SAMPLES, CHUNK_SAMPLES, ns.data(), batch_of(bi), 0, OHW_MEL_ZERO_TAIL, nullptr));
+          check(ohw_encode(e->state, batch_of(bi)));
+          decode_batch(sc, e->state, bi, ns.data());
+          collect(sc, batch_of(bi));
         }
-      } else {
+      } else if (schedule == OHW_SCHEDULE_PIPELINE) {
         // mel + encoder + cross-K/V of batch i+1 (MFMA-bound) run beside the greedy decode of batch i (HBM- and
         // latency-bound) on disjoint CUs; the first front end and the last decode have the device to themselves
-        ohw_state* sts[2] = {e->state, e->state2};
+        Scratch sc(e->max_batch, max_tok);
         std::vector<int32_t> ns2[2] = {std::vector<int32_t>((size_t)e->max_batch), std::vector<int32_t>((size_t)e->max_batch)};
-        auto restore = [&] { (void)ohw_state_set_stream(e->state, nullptr); (void)ohw_state_set_stream(e->state2, nullptr); };
-        auto front = [&](int64_t bi, void* stream) {
-          ohw_state* st = sts[bi & 1];
-          std::vector<int32_t>& nsv = ns2[bi & 1];
-          const int64_t w0 = bi * e->max_batch;
-          const int B = batch_of(bi);
-          for (int b = 0; b < B; ++b) nsv[(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + b) * CHUNK_SAMPLES);
-          check(ohw_state_set_stream(st, stream));
-          check(ohw_mel(st, samples + w0 * CHUNK_SAMPLES, CHUNK_SAMPLES, nsv.data(), B, 0, OHW_MEL_ZERO_TAIL, nullptr));
-          check(ohw_encode(st, B));
-        };
         try {
-          front(0, e->s_full);
+          front(0, e->states[0], e->s_full, ns2[0]);
           void* last_front = e->s_full;
           for (int64_t bi = 0; bi < n_batches; ++bi) {
             const bool more = bi + 1 < n_batches;
@@ -379,11 +426,59 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
             check(ohw_stream_wait(dstream, last_front));            // this batch's cross-K/V before its decode
             if (more) {
               check(ohw_stream_wait(e->s_enc, last_front));
-              front(bi + 1, e->s_enc);
+              front(bi + 1, e->states[(bi + 1) & 1], e->s_enc, ns2[(bi + 1) & 1]);
               last_front = e->s_enc;
             }
-            check(ohw_state_set_stream(sts[bi & 1], dstream));
-            decode_batch(sts[bi & 1], bi, ns2[bi & 1].data());
+            check(ohw_state_set_stream(e->states[bi & 1], dstream));
+            decode_batch(sc, e->states[bi & 1], bi, ns2[bi & 1].data());
+            collect(sc, batch_of(bi));
+          }
+        } catch (...) {
+          (void)hipDeviceSynchronize();
+          restore();
+          throw;
+        }
+        restore();
+      } else {
+        // LANES: groups of L batches.  Their front ends run one after the other on every CU (MFMA-bound: nothing to gain
+        // from sharing the chip), then their L decodes run side by side, each on its own CU-masked stream driven by its own
+        // host thread: a decode alternates an HBM-bound kernel (cross-attention) with a chain of latency-bound ones, and L
+        // of them together keep HBM busy (4 decodes of 32 large-v3 windows: 1.45-1.56x the rate of one after the other,
+        // tools/decode_overlap_probe.py).  Results are identical to the sequential schedule: the kernels' arithmetic
+        // does not depend on the CU budget.
+        const int L = (int)e->lane_streams.size();
+        std::vector<std::unique_ptr<Scratch>> scs;
+        std::vector<std::vector<int32_t>> nss((size_t)L, std::vector<int32_t>((size_t)e->max_batch));
+        for (int i = 0; i < L; ++i) scs.emplace_back(new Scratch(e->max_batch, max_tok));
+        try {
+          for (int64_t g0 = 0; g0 < n_batches; g0 += L) {
+            const int grp = (int)std::min<int64_t>(L, n_batches - g0);
+            for (int j = 0; j < grp; ++j) front(g0 + j, e->states[(size_t)j], e->s_full, nss[(size_t)j]);
+            if (grp == 1) {
+              decode_batch(*scs[0], e->states[0], g0, nss[0].data());
+              collect(*scs[0], batch_of(g0));
+              continue;
+            }
+            std::vector<std::string> errs((size_t)grp);
+            std::vector<std::thread> th;
+            for (int j = 0; j < grp; ++j) {
+              check(ohw_stream_wait(e->lane_streams[(size_t)j], e->s_full));
+              check(ohw_state_set_stream(e->states[(size_t)j], e->lane_streams[(size_t)j]));
+            }
+            for (int j = 0; j < grp; ++j)
+              th.emplace_back([&, j] {
+                try {
+                  decode_batch(*scs[(size_t)j], e->states[(size_t)j], g0 + j, nss[(size_t)j].data());
+                } catch (const std::exception& ex) {
+                  errs[(size_t)j] = ex.what()[0] ? ex.what() : "unknown error";
+                }
+              });
+            for (auto& t : th) t.join();
+            for (int j = 0; j < grp; ++j) if (!errs[(size_t)j].empty()) throw Error(OHW_E_TRANSCRIBE, errs[(size_t)j]);
+            for (int j = 0; j < grp; ++j) {
+              check(ohw_stream_wait(e->s_full, e->lane_streams[(size_t)j]));
+              collect(*scs[(size_t)j], batch_of(g0 + j));
+            }
           }
         } catch (...) {
           (void)hipDeviceSynchronize();
@@ -596,7 +691,8 @@ int ohw_engine_new(const char* model_path, const char* language, int translate, 
 void ohw_engine_free(ohw_engine* e) {
   if (!e) return;
   ohw_state_free(e->state);
-  if (e->state2) ohw_state_free(e->state2);
+  for (size_t i = 1; i < e->states.size(); ++i) ohw_state_free(e->states[i]);
+  for (void* ls : e->lane_streams) (void)ohw_stream_destroy(ls);
   for (void* st : {e->s_full, e->s_enc, e->s_dec}) if (st) (void)ohw_stream_destroy(st);
   ohw_ctx_free(e->ctx);
   delete e;
@@ -670,6 +766,13 @@ int ohw_engine_last_quality(ohw_engine* e, const ohw_window_quality** q, int* n_
   if (!e || !q || !n_windows) return OHW_E_INVALID_ARG;
   *q = e->last_quality.data();
   *n_windows = (int)e->last_quality.size();
+  return OHW_OK;
+}
+
+int ohw_engine_set_schedule(ohw_engine* e, int schedule, int lanes) {
+  if (!e || schedule < OHW_SCHEDULE_SEQUENTIAL || schedule > OHW_SCHEDULE_LANES || lanes < 0 || lanes > 16) return OHW_E_INVALID_ARG;
+  e->schedule = schedule;
+  if (lanes > 0) e->lanes = lanes;
   return OHW_OK;
 }
 

@@ -1,6 +1,7 @@
 // host_engine.hpp — the engine object behind ohw_engine_* (host_engine.cpp) and the multi-device pool (pool.cpp).
 #pragma once
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -17,8 +18,11 @@ struct ohw_engine {
   std::vector<ohw_window_quality> last_quality;
   // two batches in flight for audio longer than max_batch windows (include/ohw.h, ohw_stream_create): a second state
   // and three streams, made on first use; enc_cus = 0 keeps the batches strictly one after the other
-  ohw_state* state2 = nullptr;
+  std::vector<ohw_state*> states;        // states[0] == state; the others are made on the first long input
+  std::vector<void*> lane_streams;       // LANES schedule: one CU-masked stream per decode lane
   void* s_full = nullptr; void* s_enc = nullptr; void* s_dec = nullptr;
+  int schedule = OHW_SCHEDULE_LANES;     // how audio longer than max_batch windows is overlapped (include/ohw.h)
+  int lanes = 4;                         // decodes side by side in the LANES schedule
   int enc_cus = 96;
   int device = 0;
   ohw_decode_policy policy{0.2f, 2.4f, -1.0f, 0.6f};

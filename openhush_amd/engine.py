@@ -28,6 +28,7 @@ CHUNK_FRAMES = 3000
 OHW_DTYPE_BF16, OHW_DTYPE_F16 = 0, 1
 OHW_MEL_REFLECT, OHW_MEL_ZERO_TAIL = 0, 1
 OHW_WINDOW_FIXED, OHW_WINDOW_SEEK = 0, 1
+OHW_SCHEDULE_SEQUENTIAL, OHW_SCHEDULE_PIPELINE, OHW_SCHEDULE_LANES = 0, 1, 2
 EPI_BIAS_T, EPI_BIAS_GELU_T, EPI_BIAS_RESID_F32, EPI_F32 = 0, 1, 2, 4
 
 OHW_E_MODEL_NOT_FOUND, OHW_E_LOAD_FAILED, OHW_E_TRANSCRIBE = -3001, -3002, -3003
@@ -100,7 +101,7 @@ EXPORTS = [
     "ohw_dsp_compress", "ohw_dsp_limit", "ohw_dsp_resample_linear",
     "ohw_greedy_ex", "ohw_state_set_logit_bias", "ohw_dbg_sample",
     "ohw_decode_active", "ohw_rng_new", "ohw_rng_free", "ohw_sample_host", "ohw_default_decode_policy", "ohw_engine_set_decode_policy",
-    "ohw_engine_last_trace",
+    "ohw_engine_last_trace", "ohw_engine_set_schedule",
     "ohw_pool_create", "ohw_pool_transcribe", "ohw_pool_last_text", "ohw_pool_last_tokens", "ohw_pool_last_quality",
     "ohw_pool_set_decode_policy", "ohw_pool_n_devices", "ohw_pool_broadcast_kind", "ohw_pool_engine", "ohw_pool_free",
 ]
@@ -210,6 +211,7 @@ def lib():
         L.ohw_engine_transcribe.argtypes = [vp, fp, C.c_int64, C.c_uint32, C.c_char_p, C.c_size_t, C.c_char_p,
                                             C.POINTER(C.c_uint64), C.POINTER(AudioInfo)]
         L.ohw_engine_set_window_mode.argtypes = [vp, C.c_int]
+        L.ohw_engine_set_schedule.argtypes = [vp, C.c_int, C.c_int]
         L.ohw_engine_last_quality.argtypes = [vp, C.POINTER(C.POINTER(WindowQuality)), C.POINTER(C.c_int)]
         L.ohw_engine_last_text.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
         L.ohw_engine_last_tokens.argtypes = [vp, C.POINTER(ip), C.POINTER(C.c_int)]
@@ -750,6 +752,10 @@ class WhisperEngine:
     def set_window_mode(self, mode: int):
         """OHW_WINDOW_FIXED (0, default) or OHW_WINDOW_SEEK (1, whisper.cpp's timestamp-driven loop)"""
         _check(lib().ohw_engine_set_window_mode(self.h, mode))
+
+    def set_schedule(self, schedule: int, lanes: int = 0):
+        """OHW_SCHEDULE_SEQUENTIAL / _PIPELINE / _LANES (default) for audio longer than max_batch windows"""
+        _check(lib().ohw_engine_set_schedule(self.h, schedule, lanes))
 
     def last_tokens(self) -> List[int]:
         p = C.POINTER(C.c_int32)()

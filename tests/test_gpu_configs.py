@@ -160,17 +160,21 @@ def _recording(n_windows, tail=None):
 
 def test_config4_one_hour_120_windows_on_one_gpu(E, large_v3_file, monkeypatch):
     """BASELINE config #4 at full size on one GPU: 1 h = 120 windows, large-v3 dims, bf16, max_batch 32 (4 batches).
-    Two batches in flight (front end of batch i+1 beside the decode of batch i) == one batch after the other, token for
-    token; four sampled windows == the same window alone through the staged API (other kernel variants: single-m-tile
-    GEMMs, split cross-attention)."""
+    The default schedule (4 decodes side by side after 4 front ends) and round 1's two-batch pipeline == one batch after
+    the other, token for token; four sampled windows == the same window alone through the staged API (other kernel
+    variants: single-m-tile GEMMs, split cross-attention)."""
     n_win = 120
     pcm = _recording(n_win, tail=300000)
     out = {}
-    for cus in ("96", "0"):
-        monkeypatch.setenv("OHW_ENGINE_ENC_CUS", cus)
+    import time
+    for cus, sched in (("lanes", E.OHW_SCHEDULE_LANES), ("96", E.OHW_SCHEDULE_PIPELINE), ("0", E.OHW_SCHEDULE_SEQUENTIAL)):
         eng = E.WhisperEngine.new(large_v3_file, "auto", False, True, 0, E.OHW_DTYPE_BF16, 32)
         eng.set_decode_policy(temperature_inc=0.0)           # T = 0 only: the fallback ladder is a per-window host path
+        eng.set_schedule(sched)
+        eng.transcribe(E.AudioBuffer(pcm[:480000 * 70], 16000))      # warm-up: states, streams, graph captures
+        t0 = time.perf_counter()
         res = eng.transcribe(E.AudioBuffer(pcm, 16000))
+        print(f"config#4 schedule {cus}: 1 h of audio in {time.perf_counter() - t0:.2f} s")
         q = eng.last_quality()
         out[cus] = (res.text, eng.last_tokens(), [x[0] for x in q])
         if cus == "0":
@@ -194,7 +198,7 @@ def test_config4_one_hour_120_windows_on_one_gpu(E, large_v3_file, monkeypatch):
             assert agree >= 0.98 * total
             st1.close()
         eng.close()
-    assert out["96"] == out["0"]
+    assert out["96"] == out["0"] and out["lanes"] == out["0"]
     assert len(out["0"][0]) > 0
 
 
