@@ -43,7 +43,9 @@ enum {
 };
 
 /* compute dtype of weights/activations fed to MFMA (accumulation, LN, softmax, logits: fp32) */
-enum { OHW_DTYPE_BF16 = 0, OHW_DTYPE_F16 = 1 };
+/* OHW_DTYPE_AUTO (ohw_ctx_create / ohw_engine_new / ohw_pool_create only): f16 when the file stores f16 weights (ftype 1, the
+ * stock ggml-*.bin files: the weights stay exact), bf16 for f32 files.  BASELINE.json's bench dtype is bf16, chosen explicitly. */
+enum { OHW_DTYPE_AUTO = -1, OHW_DTYPE_BF16 = 0, OHW_DTYPE_F16 = 1 };
 
 /* log-mel tail convention */
 enum { OHW_MEL_REFLECT = 0 /* feature-extractor convention, pinned by goldens */,
@@ -82,6 +84,7 @@ int ohw_ctx_create(const char* model_path, int device, int dtype, ohw_ctx** out)
 /* procedural weights generated on the device (tests / bench; openhush_amd/synth.py is the spec)  */
 int ohw_ctx_create_synthetic(const ohw_hparams* hp, uint32_t seed, int device, int dtype, ohw_ctx** out);
 int ohw_ctx_info(const ohw_ctx* ctx, ohw_hparams* hp, ohw_special_tokens* tok);
+int ohw_ctx_dtype(const ohw_ctx* ctx);   /* the 16-bit type the context computes in (what OHW_DTYPE_AUTO resolved to) */
 /* ---- a loaded model as ONE device blob: the rank that read the file exports it, the caller broadcasts it (RCCL) and
  *      the other ranks import it into a shell context made from the same hparams and dtype - instead of every rank
  *      reading and repacking the file ("one ncclBroadcast of the packed weight blob at load").  A shell has
@@ -116,6 +119,43 @@ void ohw_dsp_compress(float* samples, int64_t n, uint32_t sample_rate, float thr
 int64_t ohw_dsp_limit(float* samples, int64_t n, uint32_t sample_rate, float ceiling_db, float release_ms); /* samples over the ceiling */
 /* returns the output length; with out == NULL or out_cap too small nothing is written (size query) */
 int64_t ohw_dsp_resample_linear(const float* in, int64_t n, uint32_t from_rate, uint32_t to_rate, float* out, int64_t out_cap);
+
+/* high-quality resampling: the reference's resample(.., ResamplingQuality::High) = rubato's SincFixedIn with sinc_len 256,
+ * f_cutoff 0.95, oversampling 256, linear interpolation between sub-filters, BlackmanHarris2 window, fed in chunks of 1024
+ * input samples (reference src/input/audio.rs:1007-1095).  The rubato crate is not in the reference tree: the algorithm is
+ * restated from its published design (windowed-sinc polyphase table, two nearest sub-filters blended linearly), parity
+ * unpinned.  Same size-query convention as ohw_dsp_resample_linear.                                                  */
+int64_t ohw_dsp_resample_sinc(const float* in, int64_t n, uint32_t from_rate, uint32_t to_rate, float* out, int64_t out_cap);
+
+/* ---- voice-activity segmentation, the step in front of the path in continuous mode (host code) --------
+ *      ohw_vad_state_*: the reference's VadState (src/vad/mod.rs:112-250) - per-chunk VAD results in, speech segments out;
+ *      ohw_vad_engine: its VadEngine trait (src/vad/mod.rs:34-55) as a struct of function pointers, so the host plugs in the
+ *      detector (the reference's SileroVad needs an ONNX model that is not available offline); ohw_vad_run: the daemon's
+ *      continuous-mode loop over a recording (src/daemon.rs:2062-2138); ohw_vad_energy_engine: a built-in short-time-energy
+ *      detector for tests and model-less hosts (not Silero). ------------------------------------------------------------ */
+typedef struct { int32_t enabled; float threshold; uint32_t min_silence_ms, min_speech_ms, speech_pad_ms; } ohw_vad_config;
+void ohw_default_vad_config(ohw_vad_config* c);     /* 0, 0.5, 700, 250, 30 (reference src/vad/mod.rs:76-100) */
+typedef struct { int64_t start, end; float avg_probability; } ohw_speech_segment;   /* positions in samples */
+typedef struct ohw_vad_state ohw_vad_state;
+ohw_vad_state* ohw_vad_state_new(const ohw_vad_config* cfg, uint32_t sample_rate);
+void ohw_vad_state_free(ohw_vad_state* s);
+/* returns 1 and fills *seg when a speech segment just ended, 0 otherwise, negative on a bad argument */
+int ohw_vad_state_update(ohw_vad_state* s, float probability, int is_speech, int64_t chunk_samples, ohw_speech_segment* seg);
+int ohw_vad_state_is_speech(const ohw_vad_state* s);
+int64_t ohw_vad_state_speech_start(const ohw_vad_state* s);   /* -1 when not in speech */
+void ohw_vad_state_reset(ohw_vad_state* s);
+typedef struct {
+  void* user;
+  int (*process)(void* user, const float* samples, int64_t n, float* probability);   /* 0 = ok; 16 kHz mono f32 */
+  void (*reset)(void* user);                                                           /* may be NULL */
+  int32_t chunk_size;     /* 512 for Silero */
+  uint32_t sample_rate;   /* 16000 */
+} ohw_vad_engine;
+int ohw_vad_energy_engine(float threshold_db, ohw_vad_engine* out);
+void ohw_vad_energy_engine_free(ohw_vad_engine* e);
+/* number of speech segments of a recording (all of them; at most cap are written to out), or a negative error code */
+int64_t ohw_vad_run(const ohw_vad_engine* engine, const ohw_vad_config* cfg, const float* samples, int64_t n, int64_t poll_samples,
+                    ohw_speech_segment* out, int64_t cap);
 
 /* ---- state: replaces ctx.create_state() (reference src/engine/whisper.rs:167-169) ------------- */
 /* max_batch = number of independent 30 s windows processed together (the reference: 1)           */

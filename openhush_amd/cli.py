@@ -68,7 +68,7 @@ def _transcribe_ranks(args, audio) -> int:
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     E.validate_audio(audio.samples, audio.sample_rate)
     # rank 0 reads the file, the packed weights reach the other GPUs in one RCCL broadcast
-    ctx = shard.load_model_broadcast(args.model_path, dist, world, rank, local, E.OHW_DTYPE_BF16 if args.dtype == "bf16" else E.OHW_DTYPE_F16)
+    ctx = shard.load_model_broadcast(args.model_path, dist, world, rank, local, {"auto": E.OHW_DTYPE_AUTO, "bf16": E.OHW_DTYPE_BF16, "f16": E.OHW_DTYPE_F16}[args.dtype])
     p = ctx.default_params()
     if args.language != "auto":
         p.lang_id = E.lang_code_to_id(args.language)
@@ -107,7 +107,8 @@ def main(argv=None) -> int:
     t.add_argument("--translate", action="store_true")
     t.add_argument("--format", default="text", choices=["text", "json"])
     t.add_argument("--device", default="hip:0")
-    t.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    t.add_argument("--dtype", default="auto", choices=["auto", "bf16", "f16"],
+                   help="auto (default): the model file's own precision - f16 for the stock ggml files (ftype 1), whose weights then stay exact")
     t.add_argument("--max-batch", type=int, default=8)
     args = ap.parse_args(argv)
 
@@ -126,7 +127,7 @@ def main(argv=None) -> int:
     dev = int(args.device.split(":")[1]) if ":" in args.device else 0
     t0 = time.perf_counter()
     eng = E.WhisperEngine.new(args.model_path, args.language, args.translate, use_gpu, dev,
-                              E.OHW_DTYPE_BF16 if args.dtype == "bf16" else E.OHW_DTYPE_F16, args.max_batch)
+                              {"auto": E.OHW_DTYPE_AUTO, "bf16": E.OHW_DTYPE_BF16, "f16": E.OHW_DTYPE_F16}[args.dtype], args.max_batch)
     print(f"Model loaded in {1e3 * (time.perf_counter() - t0):.0f}ms", file=sys.stderr)
     t1 = time.perf_counter()
     res = eng.transcribe(audio)

@@ -26,6 +26,12 @@ struct ApiScope {
   ApiScope(const ApiScope&) = delete;
   ApiScope& operator=(const ApiScope&) = delete;
 };
+struct ApiRelease {    // inside an ApiScope: gives the gate up while this thread only WAITS for other threads of the library
+  ApiRelease();        // (a lane that captures a graph needs the gate exclusively; a waiting holder would block it for ever)
+  ~ApiRelease();
+  ApiRelease(const ApiRelease&) = delete;
+  ApiRelease& operator=(const ApiRelease&) = delete;
+};
 struct CaptureGate {   // inside an ApiScope: shared -> exclusive for the lifetime of the object
   CaptureGate();
   ~CaptureGate();

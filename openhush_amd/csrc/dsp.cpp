@@ -7,12 +7,14 @@
 //   ohw_dsp_resample_linear <- resample_linear              (:972-990)
 //   ohw_preprocess_audio    <- TranscriptionWorker::preprocess_audio (src/queue/worker.rs:196-240), without RNNoise
 // The envelope follower and the limiter are first-order recurrences with a data-dependent branch per sample over the
+//   ohw_dsp_resample_sinc   <- resample_sinc                (:1007-1095): rubato's SincFixedIn, restated from its published design
 // WHOLE recording: one sequential chain, nothing for a GPU to parallelise - they stay on the host (about 3 ns per sample).
-// Arithmetic is in fp32 in the reference's operation order.  Not built: the rubato sinc resampler and RNNoise
-// (third-party crates, sources and model not under /root/reference).
+// Arithmetic is in fp32 in the reference's operation order.  Not built: RNNoise (the nnnoiseless crate and its trained
+// network are not under /root/reference).
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 #include "../../include/ohw.h"
 
@@ -93,6 +95,102 @@ int64_t ohw_dsp_resample_linear(const float* in, int64_t n, uint32_t from_rate, 
     out[i] = in[lo] * (1.0f - (float)frac) + in[hi] * (float)frac;
   }
   return new_len;
+}
+
+// ---- resample_sinc (reference src/input/audio.rs:1007-1095) -----------------------------------------------------------
+// The reference hands 1024-sample chunks (the last one zero-padded) to rubato::SincFixedIn<f32>(ratio, 2.0, params, 1024, 1)
+// with sinc_len 256, f_cutoff 0.95, oversampling_factor 256, SincInterpolationType::Linear, WindowFunction::BlackmanHarris2,
+// appends every chunk's output and, for the last (partial) chunk, only ceil(len * ratio) samples of it.  rubato is a
+// third-party crate that is not under /root/reference; what follows restates its algorithm as published (parity unpinned):
+//   table    y[x] = w[x] * sinc((x - T/2) * fc / F), x = 0 .. T-1, T = sinc_len * F, w = squared Blackman-Harris (periodic over T),
+//            fc = f_cutoff (times the ratio when downsampling); sub-filter F - 1 - p, tap n = y[F * n + p] / (sum(y) / F)
+//   process  the resampler keeps the previous 2 * sinc_len inputs in front of the chunk; the read position idx starts at
+//            -sinc_len / 2 and advances by 1 / ratio per output; an output is the linear blend (weight = fractional part of
+//            idx * F) of the dot products of the sinc_len inputs starting at floor(idx) with the two nearest sub-filters;
+//            a chunk's outputs stop at idx >= chunk - (sinc_len + 1) - ceil(1 / ratio); idx -= chunk for the next call.
+namespace {
+struct SincResampler {
+  static constexpr int L = 256, F = 256, CHUNK = 1024;
+  double ratio, t_ratio, last_index;
+  std::vector<float> sincs;     // [F][L]
+  std::vector<float> buf;       // [2 L + CHUNK]
+  explicit SincResampler(double r) : ratio(r), t_ratio(1.0 / r), last_index(-(double)(L / 2)), sincs((size_t)F * L), buf((size_t)2 * L + CHUNK, 0.0f) {
+    const double fc = r >= 1.0 ? 0.95 : 0.95 * r;
+    const int T = L * F;
+    std::vector<double> y((size_t)T);
+    double sum = 0.0;
+    const double PI = 3.14159265358979323846;
+    for (int x = 0; x < T; ++x) {
+      const double xf = (double)x / (double)T;
+      const double bh = 0.35875 - 0.48829 * std::cos(2.0 * PI * xf) + 0.14128 * std::cos(4.0 * PI * xf) - 0.01168 * std::cos(6.0 * PI * xf);
+      const double arg = ((double)x - (double)(T / 2)) * fc / (double)F;
+      const double sc = arg == 0.0 ? 1.0 : std::sin(PI * arg) / (PI * arg);
+      y[(size_t)x] = bh * bh * sc;
+      sum += y[(size_t)x];
+    }
+    sum /= (double)F;
+    for (int p = 0; p < F; ++p)
+      for (int n = 0; n < L; ++n) sincs[(size_t)(F - 1 - p) * L + n] = (float)(y[(size_t)(F * n + p)] / sum);   // sub-filter s = later fractional position
+  }
+  float dot(int64_t index, int sub) const {
+    const float* w = &buf[(size_t)index];
+    const float* h = &sincs[(size_t)sub * L];
+    float acc = 0.0f;
+    for (int n = 0; n < L; ++n) acc += w[n] * h[n];
+    return acc;
+  }
+  // one chunk of exactly CHUNK input samples in, its outputs appended to `out`
+  void process(const float* chunk, std::vector<float>& out) {
+    std::memmove(buf.data(), buf.data() + CHUNK, sizeof(float) * (size_t)(2 * L));
+    std::memcpy(buf.data() + 2 * L, chunk, sizeof(float) * (size_t)CHUNK);
+    const double end_idx = (double)(CHUNK - (L + 1) - (int64_t)std::ceil(t_ratio));
+    double idx = last_index;
+    while (idx < end_idx) {
+      idx += t_ratio;
+      const double fl = std::floor(idx);
+      int64_t i0 = (int64_t)fl;
+      int s0 = (int)std::floor((idx - fl) * (double)F);
+      int64_t i1 = i0;
+      int s1 = s0 + 1;
+      if (s1 >= F) { s1 -= F; i1 += 1; }
+      const double scaled = idx * (double)F;
+      const float frac = (float)(scaled - std::floor(scaled));
+      const float p0 = dot(i0 + 2 * L, s0), p1 = dot(i1 + 2 * L, s1);
+      out.push_back(p0 + frac * (p1 - p0));
+    }
+    last_index = idx - (double)CHUNK;
+  }
+};
+}  // namespace
+
+int64_t ohw_dsp_resample_sinc(const float* in, int64_t n, uint32_t from_rate, uint32_t to_rate, float* out, int64_t out_cap) {
+  if (!in || n <= 0 || from_rate == 0 || to_rate == 0) return 0;
+  if (from_rate == to_rate) {
+    if (out && out_cap >= n) std::memcpy(out, in, (size_t)n * sizeof(float));
+    return n;
+  }
+  const double ratio = (double)to_rate / (double)from_rate;
+  if (ratio > 16.0 || ratio < 1.0 / 16.0) return 0;
+  SincResampler rs(ratio);
+  std::vector<float> res, piece, padded((size_t)SincResampler::CHUNK);
+  res.reserve((size_t)((double)n * ratio) + 1024);
+  for (int64_t pos = 0; pos < n; pos += SincResampler::CHUNK) {
+    const int64_t len = n - pos < SincResampler::CHUNK ? n - pos : SincResampler::CHUNK;
+    std::memcpy(padded.data(), in + pos, sizeof(float) * (size_t)len);
+    if (len < SincResampler::CHUNK) std::memset(padded.data() + len, 0, sizeof(float) * (size_t)(SincResampler::CHUNK - len));
+    piece.clear();
+    rs.process(padded.data(), piece);
+    size_t take = piece.size();
+    if (len < SincResampler::CHUNK) {                              // the last, partial chunk: its proportional share only
+      const size_t expected = (size_t)std::ceil((double)len * ratio);
+      if (expected < take) take = expected;
+    }
+    res.insert(res.end(), piece.begin(), piece.begin() + (std::ptrdiff_t)take);
+  }
+  const int64_t total = (int64_t)res.size();
+  if (!out || out_cap < total) return total;
+  std::memcpy(out, res.data(), sizeof(float) * (size_t)total);
+  return total;
 }
 
 void ohw_default_preprocess_config(ohw_preprocess_config* c) {

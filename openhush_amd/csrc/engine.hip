@@ -27,6 +27,8 @@ static std::shared_mutex g_api_mu;
 static thread_local int g_api_depth = 0;
 ApiScope::ApiScope() { if (g_api_depth++ == 0) g_api_mu.lock_shared(); }
 ApiScope::~ApiScope() { if (--g_api_depth == 0) g_api_mu.unlock_shared(); }
+ApiRelease::ApiRelease() { if (g_api_depth > 0) g_api_mu.unlock_shared(); }
+ApiRelease::~ApiRelease() { if (g_api_depth > 0) g_api_mu.lock_shared(); }
 CaptureGate::CaptureGate() { g_api_mu.unlock_shared(); g_api_mu.lock(); }
 CaptureGate::~CaptureGate() { g_api_mu.unlock(); g_api_mu.lock_shared(); }
 
@@ -416,6 +418,8 @@ int ohw_ctx_info(const ohw_ctx* ctx, ohw_hparams* hp, ohw_special_tokens* tok) {
     if (tok) *tok = ctx->tok;
   });
 }
+
+int ohw_ctx_dtype(const ohw_ctx* ctx) { return ctx ? ctx->dtype : OHW_E_INVALID_ARG; }
 
 int ohw_token_text(const ohw_ctx* ctx, int32_t id, const char** text) {
   if (!ctx || id < 0 || (size_t)id >= ctx->vocab.size()) { if (text) *text = ""; return 0; }

@@ -473,7 +473,10 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
                   errs[(size_t)j] = ex.what()[0] ? ex.what() : "unknown error";
                 }
               });
-            for (auto& t : th) t.join();
+            {
+              ApiRelease wait_only;        // the lanes take the library's gate themselves (exclusively while one captures its graph)
+              for (auto& t : th) t.join();
+            }
             for (int j = 0; j < grp; ++j) if (!errs[(size_t)j].empty()) throw Error(OHW_E_TRANSCRIBE, errs[(size_t)j]);
             for (int j = 0; j < grp; ++j) {
               check(ohw_stream_wait(e->s_full, e->lane_streams[(size_t)j]));

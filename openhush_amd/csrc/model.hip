@@ -342,13 +342,17 @@ static void load_file_typed(ohw_ctx* c, FileReader& fr) {
 ohw_ctx* ctx_from_file(const char* path, int device, int dtype) {
   struct stat st;
   if (!path || stat(path, &st) != 0) throw Error(OHW_E_MODEL_NOT_FOUND, std::string("model not found at ") + (path ? path : "(null)"));
-  if (dtype != OHW_DTYPE_BF16 && dtype != OHW_DTYPE_F16) throw Error(OHW_E_INVALID_ARG, "dtype must be OHW_DTYPE_BF16 or OHW_DTYPE_F16");
+  if (dtype != OHW_DTYPE_BF16 && dtype != OHW_DTYPE_F16 && dtype != OHW_DTYPE_AUTO)
+    throw Error(OHW_E_INVALID_ARG, "dtype must be OHW_DTYPE_AUTO, OHW_DTYPE_BF16 or OHW_DTYPE_F16");
   FileReader fr(path);
   if (!fr.f) throw Error(OHW_E_LOAD_FAILED, std::string("cannot open ") + path);
   if (fr.get<uint32_t>() != 0x67676d6cu) throw Error(OHW_E_LOAD_FAILED, "not a ggml model file (bad magic)");
   std::unique_ptr<ohw_ctx> c(new ohw_ctx());
   fr.read(&c->hp, sizeof c->hp);
   check_hparams(c->hp);
+  // AUTO: the file's own weight precision.  The stock ggml-*.bin files store f16 (ftype 1): f16 keeps them EXACT (bf16 would
+  // drop 3 mantissa bits of every weight for +1 % throughput); f32 files (ftype 0) get bf16's range
+  if (dtype == OHW_DTYPE_AUTO) dtype = c->hp.ftype == 1 ? OHW_DTYPE_F16 : OHW_DTYPE_BF16;
   const int32_t n_mel = fr.get<int32_t>(), n_fft = fr.get<int32_t>();
   if (n_mel != c->hp.n_mels || n_fft != N_FREQ) throw Error(OHW_E_LOAD_FAILED, "mel filterbank shape mismatch");
   std::vector<float> filters((size_t)n_mel * n_fft);

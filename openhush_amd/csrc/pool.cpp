@@ -160,6 +160,7 @@ int ohw_pool_create(const char* model_path, const char* language, int translate,
       if (rc != OHW_OK) throw Error(rc == OHW_E_NO_GPU || rc == OHW_E_OOM ? rc : OHW_E_LOAD_FAILED, "Failed to load model: " + g_last_error);
       ohw_hparams hp;
       (void)ohw_ctx_info(ctxs[0], &hp, nullptr);
+      dtype = ohw_ctx_dtype(ctxs[0]);                       // what OHW_DTYPE_AUTO resolved to
       for (int i = 1; i < n_devices; ++i) {
         rc = ohw_ctx_create_shell(&hp, device_ids[i], dtype, &ctxs[(size_t)i]);
         if (rc != OHW_OK) throw Error(rc, "pool: device " + std::to_string(device_ids[i]) + ": " + g_last_error);

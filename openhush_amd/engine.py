@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("OHW_LIB") or os.path.join(_HERE, "libohw.so")   # OHW
 CHUNK_SAMPLES = 480000
 CHUNK_FRAMES = 3000
 
-OHW_DTYPE_BF16, OHW_DTYPE_F16 = 0, 1
+OHW_DTYPE_AUTO, OHW_DTYPE_BF16, OHW_DTYPE_F16 = -1, 0, 1
 OHW_MEL_REFLECT, OHW_MEL_ZERO_TAIL = 0, 1
 OHW_WINDOW_FIXED, OHW_WINDOW_SEEK = 0, 1
 OHW_SCHEDULE_SEQUENTIAL, OHW_SCHEDULE_PIPELINE, OHW_SCHEDULE_LANES = 0, 1, 2
@@ -70,6 +70,24 @@ class GreedyResult(C.Structure):
                 ("token_logprobs", C.POINTER(C.c_float)), ("ended_by_eot", C.POINTER(C.c_int32)), ("no_speech_prob", C.POINTER(C.c_float))]
 
 
+class VadConfig(C.Structure):
+    """reference src/vad/mod.rs:57-100"""
+    _fields_ = [("enabled", C.c_int32), ("threshold", C.c_float), ("min_silence_ms", C.c_uint32), ("min_speech_ms", C.c_uint32),
+                ("speech_pad_ms", C.c_uint32)]
+
+
+class SpeechSegment(C.Structure):
+    _fields_ = [("start", C.c_int64), ("end", C.c_int64), ("avg_probability", C.c_float)]
+
+
+VAD_PROCESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_float))
+VAD_RESET_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class VadEngineC(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("process", VAD_PROCESS_FN), ("reset", VAD_RESET_FN), ("chunk_size", C.c_int32), ("sample_rate", C.c_uint32)]
+
+
 class WindowQuality(C.Structure):
     _fields_ = [("n_tokens", C.c_int32), ("avg_logprob", C.c_float), ("entropy", C.c_float), ("would_fallback", C.c_int32),
                 ("temperature", C.c_float), ("no_speech_prob", C.c_float), ("no_speech", C.c_int32), ("seek_delta", C.c_int32),
@@ -101,7 +119,10 @@ EXPORTS = [
     "ohw_dsp_compress", "ohw_dsp_limit", "ohw_dsp_resample_linear",
     "ohw_greedy_ex", "ohw_state_set_logit_bias", "ohw_dbg_sample",
     "ohw_decode_active", "ohw_rng_new", "ohw_rng_free", "ohw_sample_host", "ohw_default_decode_policy", "ohw_engine_set_decode_policy",
-    "ohw_engine_last_trace", "ohw_engine_set_schedule",
+    "ohw_engine_last_trace", "ohw_engine_set_schedule", "ohw_ctx_dtype",
+    "ohw_dsp_resample_sinc", "ohw_default_vad_config", "ohw_vad_state_new", "ohw_vad_state_free", "ohw_vad_state_update",
+    "ohw_vad_state_is_speech", "ohw_vad_state_speech_start", "ohw_vad_state_reset", "ohw_vad_energy_engine", "ohw_vad_energy_engine_free",
+    "ohw_vad_run",
     "ohw_pool_create", "ohw_pool_transcribe", "ohw_pool_last_text", "ohw_pool_last_tokens", "ohw_pool_last_quality",
     "ohw_pool_set_decode_policy", "ohw_pool_n_devices", "ohw_pool_broadcast_kind", "ohw_pool_engine", "ohw_pool_free",
 ]
@@ -151,6 +172,7 @@ def lib():
         L.ohw_ctx_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
         L.ohw_ctx_create_synthetic.argtypes = [C.POINTER(HParams), C.c_uint32, C.c_int, C.c_int, C.POINTER(vp)]
         L.ohw_ctx_info.argtypes = [vp, C.POINTER(HParams), C.POINTER(SpecialTokens)]
+        L.ohw_ctx_dtype.argtypes = [vp]
         L.ohw_ctx_create_shell.argtypes = [C.POINTER(HParams), C.c_int, C.c_int, C.POINTER(vp)]
         L.ohw_ctx_blob_size.argtypes = [vp]
         L.ohw_ctx_blob_size.restype = C.c_size_t
@@ -178,6 +200,25 @@ def lib():
         L.ohw_dsp_limit.restype = C.c_int64
         L.ohw_dsp_resample_linear.argtypes = [fp, C.c_int64, C.c_uint32, C.c_uint32, fp, C.c_int64]
         L.ohw_dsp_resample_linear.restype = C.c_int64
+        L.ohw_dsp_resample_sinc.argtypes = [fp, C.c_int64, C.c_uint32, C.c_uint32, fp, C.c_int64]
+        L.ohw_dsp_resample_sinc.restype = C.c_int64
+        L.ohw_default_vad_config.argtypes = [C.POINTER(VadConfig)]
+        L.ohw_default_vad_config.restype = None
+        L.ohw_vad_state_new.argtypes = [C.POINTER(VadConfig), C.c_uint32]
+        L.ohw_vad_state_new.restype = vp
+        L.ohw_vad_state_free.argtypes = [vp]
+        L.ohw_vad_state_free.restype = None
+        L.ohw_vad_state_update.argtypes = [vp, C.c_float, C.c_int, C.c_int64, C.POINTER(SpeechSegment)]
+        L.ohw_vad_state_is_speech.argtypes = [vp]
+        L.ohw_vad_state_speech_start.argtypes = [vp]
+        L.ohw_vad_state_speech_start.restype = C.c_int64
+        L.ohw_vad_state_reset.argtypes = [vp]
+        L.ohw_vad_state_reset.restype = None
+        L.ohw_vad_energy_engine.argtypes = [C.c_float, C.POINTER(VadEngineC)]
+        L.ohw_vad_energy_engine_free.argtypes = [C.POINTER(VadEngineC)]
+        L.ohw_vad_energy_engine_free.restype = None
+        L.ohw_vad_run.argtypes = [C.POINTER(VadEngineC), C.POINTER(VadConfig), fp, C.c_int64, C.c_int64, C.POINTER(SpeechSegment), C.c_int64]
+        L.ohw_vad_run.restype = C.c_int64
         L.ohw_stream_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.ohw_stream_destroy.argtypes = [vp]
         L.ohw_stream_wait.argtypes = [vp, vp]
@@ -323,6 +364,10 @@ class Context:
         h = C.c_void_p()
         _check(lib().ohw_ctx_create_shell(C.byref(hp), device, dtype, C.byref(h)))
         return cls(h.value)
+
+    @property
+    def dtype(self) -> int:
+        return int(lib().ohw_ctx_dtype(self.h))
 
     def blob_size(self) -> int:
         return int(lib().ohw_ctx_blob_size(self.h))
@@ -659,6 +704,78 @@ def resample_linear(samples: np.ndarray, from_rate: int, to_rate: int) -> np.nda
     if n:
         lib().ohw_dsp_resample_linear(_fp(x), x.size, from_rate, to_rate, _fp(out), n)
     return out
+
+
+def resample_sinc(samples: np.ndarray, from_rate: int, to_rate: int) -> np.ndarray:
+    """resample(.., ResamplingQuality::High) of the reference (src/input/audio.rs:1007-1095): rubato's sinc resampler restated"""
+    x = np.ascontiguousarray(samples, dtype=np.float32)
+    if x.size == 0:
+        return x.copy()
+    n = int(lib().ohw_dsp_resample_sinc(_fp(x), x.size, from_rate, to_rate, C.cast(None, C.POINTER(C.c_float)), 0))
+    out = np.empty(n, np.float32)
+    if n:
+        lib().ohw_dsp_resample_sinc(_fp(x), x.size, from_rate, to_rate, _fp(out), n)
+    return out
+
+
+def default_vad_config() -> VadConfig:
+    c = VadConfig()
+    lib().ohw_default_vad_config(C.byref(c))
+    return c
+
+
+class VadState:
+    """reference src/vad/mod.rs:112-250"""
+    def __init__(self, config: VadConfig, sample_rate: int = 16000):
+        self.h = C.c_void_p(lib().ohw_vad_state_new(C.byref(config), sample_rate))
+
+    def update(self, probability: float, is_speech: bool, chunk_samples: int):
+        """the completed (start, end, avg_probability) when speech just ended, else None"""
+        seg = SpeechSegment()
+        rc = lib().ohw_vad_state_update(self.h, probability, int(is_speech), chunk_samples, C.byref(seg))
+        return (int(seg.start), int(seg.end), float(seg.avg_probability)) if rc == 1 else None
+
+    def is_speech(self) -> bool:
+        return bool(lib().ohw_vad_state_is_speech(self.h))
+
+    def speech_start(self):
+        v = int(lib().ohw_vad_state_speech_start(self.h))
+        return None if v < 0 else v
+
+    def reset(self):
+        lib().ohw_vad_state_reset(self.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().ohw_vad_state_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def vad_segments(samples: np.ndarray, config: VadConfig, poll_samples: int = 8000, process=None, energy_threshold_db: float = -40.0):
+    """ohw_vad_run over a recording: `process(samples) -> probability` is the VadEngine hook (a Python callable here; the
+    built-in energy detector when None).  Returns [(start, end, avg_probability)]."""
+    x = np.ascontiguousarray(samples, dtype=np.float32)
+    eng = VadEngineC()
+    keep = None
+    if process is None:
+        _check(lib().ohw_vad_energy_engine(energy_threshold_db, C.byref(eng)))
+    else:
+        def _proc(user, ptr, n, out):
+            out[0] = float(process(np.ctypeslib.as_array(ptr, shape=(n,)).copy()))
+            return 0
+        keep = VAD_PROCESS_FN(_proc)
+        eng.process, eng.reset, eng.chunk_size, eng.sample_rate = keep, VAD_RESET_FN(0), 512, 16000
+    cap = max(16, x.size // 1600)
+    segs = (SpeechSegment * cap)()
+    n = int(lib().ohw_vad_run(C.byref(eng), C.byref(config), _fp(x) if x.size else C.cast(None, C.POINTER(C.c_float)), x.size, poll_samples, segs, cap))
+    if process is None:
+        lib().ohw_vad_energy_engine_free(C.byref(eng))
+    if n < 0:
+        _check(n)
+    return [(int(segs[i].start), int(segs[i].end), float(segs[i].avg_probability)) for i in range(min(n, cap))]
 
 
 @dataclasses.dataclass

@@ -110,13 +110,14 @@ def load_model_broadcast(model_path: str, dist, world: int, rank: int, device_in
     dev = torch.device("cuda", device_index)
     # word 0 = status of rank 0's load (0 ok, else the library's error code), then the 11 hyper-parameters: every rank
     # learns of a failed load in the same broadcast and raises, instead of waiting in the blob broadcast for the timeout
-    hp_t = torch.zeros(12, dtype=torch.int32)
+    hp_t = torch.zeros(13, dtype=torch.int32)        # status, 11 hyper-parameters, the dtype rank 0 resolved (OHW_DTYPE_AUTO)
     ctx = None
     err = None
     if rank == 0:
         try:
             ctx = E.Context.from_file(model_path, device_index, dtype)
-            hp_t[1:] = torch.tensor(ctx.hp.as_list(), dtype=torch.int32)
+            hp_t[1:12] = torch.tensor(ctx.hp.as_list(), dtype=torch.int32)
+            hp_t[12] = ctx.dtype
         except E.WhisperError as ex:
             err = ex
             hp_t[0] = int(ex.code) if ex.code else -1
@@ -132,7 +133,7 @@ def load_model_broadcast(model_path: str, dist, world: int, rank: int, device_in
             raise err
         raise E.LoadFailed(status, f"rank 0 could not load {model_path} (code {status})")
     if rank != 0:
-        ctx = E.Context.shell([int(v) for v in hp_t.cpu()[1:]], device_index, dtype)
+        ctx = E.Context.shell([int(v) for v in hp_t.cpu()[1:12]], device_index, int(hp_t.cpu()[12]))
     n = ctx.blob_size()
     blob = torch.empty(n, dtype=torch.uint8, device=dev)
     if rank == 0:
