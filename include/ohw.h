@@ -251,6 +251,22 @@ typedef struct {
 } ohw_greedy_result;
 int ohw_greedy_ex(ohw_state* st, const ohw_sample_params* p, int batch, int max_tokens, const ohw_greedy_result* out);
 
+/* beam search for the windows of the last ohw_encode (BASELINE.json config #5: beam = 5, hipGraph-captured decoder step).
+ * The reference never uses one (Greedy{best_of:1}, src/engine/whisper.rs:243); the rule is the published Whisper
+ * BeamSearchDecoder: every live beam proposes its beam_size + 1 most likely next tokens after the same logits filter, a
+ * window's candidates are ranked by cumulative log-probability, sequences ending in end-of-text go to its finished pool
+ * (at most beam_size), the best beam_size others become the new beams; the result is the candidate with the best
+ * cumulative log-probability per token.  Device-resident like ohw_greedy: beam j of window w is decoder row w * K + j, the
+ * K rows of a window stream its cross K/V once and share their common past through a slot table (no K/V copies); one
+ * iteration {decoder step, top-k, update} is captured as a hipGraph and replayed.  Needs max_batch >= n_windows * beam_size. */
+typedef struct {
+  int32_t* tokens;      /* [n_windows][max_tokens] the best sequence, end-of-text not stored */
+  int32_t* n_tokens;    /* [n_windows] */
+  float* sum_logprob;   /* [n_windows] or NULL: its cumulative log-probability (end-of-text's included when it ended so) */
+  int32_t* n_finished;  /* [n_windows] or NULL: sequences that reached end-of-text */
+} ohw_beam_result;
+int ohw_beam_search(ohw_state* st, const ohw_sample_params* p, int n_windows, int beam_size, int max_tokens, const ohw_beam_result* out);
+
 /* additive bias on every logits row before the filter, bias[n_vocab] (host; copied), NULL clears it.  This is the
  * engine's form of whisper.cpp's logits_filter_callback (whisper_full_params; the reference sets none,
  * src/engine/whisper.rs:243-263, so the default is no bias); tests use it to make end-of-text and timestamps win. */

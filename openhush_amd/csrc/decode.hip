@@ -615,10 +615,12 @@ void launch_dec_gemm(const DecGemmParams& p, int epilogue, hipStream_t s) {
 template <typename T>
 __global__ __launch_bounds__(64) void self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
                                                        const int32_t* __restrict__ n_past, T* __restrict__ out, int n_new,
-                                                       int n_head, int n_ctx) {
+                                                       int n_head, int n_ctx, const int32_t* __restrict__ kv_slot) {
   // One wave per (row, head).  Keys are processed in chunks of 64: lane j owns key (chunk*64 + j) for the
   // score, lane = dh for P.V.  Every global load of a chunk (the lane's K row: 8 x 16 B, and the chunk's V
   // column slice: 64 x 2 B) is requested before anything waits: one memory round trip per chunk.
+  // kv_slot (beam search, else null): [rows][n_ctx] - the cache row that holds position j of this row's sequence: beams
+  // that continue another beam share its past through this table instead of copying K/V.
   __shared__ float qs[64];
   __shared__ float ps[64];
   const int lane = threadIdx.x;
@@ -628,22 +630,26 @@ __global__ __launch_bounds__(64) void self_attn_kernel(const T* __restrict__ q, 
   TRACE(2, 0);
   int n_keys = n_past[b] + i + 1;
   if (n_keys > n_ctx) n_keys = n_ctx;
-  const T* kb = kc + (((int64_t)b * n_head + h) * n_ctx << 6);
-  const T* vb = vc + (((int64_t)b * n_head + h) * n_ctx << 6);
+  const int64_t row_stride = (int64_t)n_head * n_ctx << 6;
+  const T* kb = kc + ((int64_t)h * n_ctx << 6);
+  const T* vb = vc + ((int64_t)h * n_ctx << 6);
+  const int32_t* slots = kv_slot ? kv_slot + (int64_t)b * n_ctx : nullptr;
   qs[lane] = (float)q[(int64_t)m * d + h * 64 + lane] * 0.125f;
   float m_run = -INFINITY, l_run = 0.f, o = 0.f;
   for (int c0 = 0; c0 < n_keys; c0 += 64) {
     const int nk = n_keys - c0 < 64 ? n_keys - c0 : 64;
     const int jk = lane < nk ? c0 + lane : c0;          // clamped: unconditional loads
+    const int sk = slots ? slots[jk] : b;
     vec8_t<T> kr[8];
-    const vec8_t<T>* kp = (const vec8_t<T>*)(kb + ((int64_t)jk << 6));
+    const vec8_t<T>* kp = (const vec8_t<T>*)(kb + sk * row_stride + ((int64_t)jk << 6));
 #pragma unroll
     for (int c = 0; c < 8; ++c) kr[c] = kp[c];
     T vr[64];
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
       const int jj = j < nk ? c0 + j : c0;
-      vr[j] = vb[((int64_t)jj << 6) + lane];
+      const int sv = slots ? slots[jj] : b;
+      vr[j] = vb[sv * row_stride + ((int64_t)jj << 6) + lane];
     }
     __syncthreads();   // qs (first chunk) / ps of the previous chunk consumed
     float sc = 0.f;
@@ -669,9 +675,9 @@ __global__ __launch_bounds__(64) void self_attn_kernel(const T* __restrict__ q, 
 }
 template <typename T>
 void launch_self_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* n_past, void* out, int M, int n_new,
-                      int n_head, int n_ctx, hipStream_t s) {
+                      int n_head, int n_ctx, hipStream_t s, const int32_t* kv_slot) {
   hipLaunchKernelGGL((self_attn_kernel<T>), dim3(n_head, M), dim3(64), 0, s, (const T*)q, (const T*)k_cache, (const T*)v_cache, n_past,
-                     (T*)out, n_new, n_head, n_ctx);
+                     (T*)out, n_new, n_head, n_ctx, kv_slot);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -910,9 +916,8 @@ __global__ __launch_bounds__(XA_THREADS) void cross_attn_rows_kernel(const T* __
     }
   }
   __syncthreads();
-  // wave i finishes row i (NQ <= 4 waves)
-  if (wave < NQ) {
-    const int i = wave;
+  // wave i finishes row i (and row i + 4 when NQ = 5)
+  for (int i = wave; i < NQ; i += 4) {
     const float mn = fmaxf(fmaxf(red_m[i][0], red_m[i][1]), fmaxf(red_m[i][2], red_m[i][3]));
     float l = 0.f, o = 0.f;
 #pragma unroll
@@ -927,7 +932,21 @@ __global__ __launch_bounds__(XA_THREADS) void cross_attn_rows_kernel(const T* __
 
 template <typename T>
 void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out, int M, int n_new, int n_head, int t_len, float* partials,
-                       unsigned* tickets, int max_split_rows, const int32_t* done, hipStream_t s) {
+                       unsigned* tickets, int max_split_rows, const int32_t* done, hipStream_t s, int kv_group) {
+  // beam search: kv_group consecutive rows are the beams of ONE window and read the same cross K/V: one workgroup per
+  // (window, head) streams it once for all of them (done: per window)
+  if (kv_group > 1) {
+    if (n_new != 1 || M % kv_group != 0 || kv_group > 5) throw Error(OHW_E_INVALID_ARG, "cross-attention: beams are single-token rows, at most 5 per window");
+    const dim3 grid(n_head, M / kv_group);
+    switch (kv_group) {
+      case 2: hipLaunchKernelGGL((cross_attn_rows_kernel<T, 2>), grid, dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_head, t_len, done); break;
+      case 3: hipLaunchKernelGGL((cross_attn_rows_kernel<T, 3>), grid, dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_head, t_len, done); break;
+      case 4: hipLaunchKernelGGL((cross_attn_rows_kernel<T, 4>), grid, dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_head, t_len, done); break;
+      default: hipLaunchKernelGGL((cross_attn_rows_kernel<T, 5>), grid, dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_head, t_len, done); break;
+    }
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   // fewer (row, head) pairs than two per CU: cut the keys (at most 8 slices, each at least a few hundred keys)
   int ks = 1;
   if (partials && tickets && M <= max_split_rows) {
@@ -1143,11 +1162,213 @@ void launch_sampler(const SamplerParams& p, hipStream_t s) {
   HIP_CHECK(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------
+// beam search (BASELINE.json config #5).  The reference never uses beam search (Greedy{best_of:1},
+// src/engine/whisper.rs:243); the rule restated here is the published Whisper BeamSearchDecoder (openai/whisper
+// decoding.py): every live beam proposes its beam_size + 1 most likely next tokens (after the same logits filter),
+// the candidates of a window are ranked by cumulative log-probability, sequences that end in end-of-text move to the
+// window's finished pool (at most beam_size of them), the best beam_size others become the new beams.
+// Rows: beam j of window w is decoder row w * K + j; the K rows of a window share its cross K/V (cross_attn_rows_kernel)
+// and share their common past through the kv_slot table of self_attn_kernel instead of copying K/V.
+// ------------------------------------------------------------------------------------------------
+constexpr int BEAM_THREADS = 1024;
+constexpr int BEAM_PER_THREAD = 52;     // 1024 * 52 >= 51866
+
+// one workgroup per row: masked log-softmax of the row, then its K + 1 best tokens (ties: lowest index)
+__global__ __launch_bounds__(BEAM_THREADS) void beam_topk_kernel(SamplerParams p, BeamParams bp, int first) {
+  __shared__ float red_v[BEAM_THREADS / 64];
+  __shared__ int red_i[BEAM_THREADS / 64];
+  __shared__ float sh_m, sh_lse, sh_tsm, sh_txt;
+  __shared__ int sh_pick;
+  const int tid = threadIdx.x;
+  // the first step reads the prompt pass's logits: one row per WINDOW, candidates go to the window's beam 0
+  const int lrow = blockIdx.x;
+  const int row = first ? lrow * bp.K : lrow;
+  const int w = row / bp.K;
+  if (bp.win_done[w]) return;
+  const float* lg = p.logits + (int64_t)lrow * p.ld;
+  const int32_t* toks = p.tokens + (int64_t)row * p.max_tokens;
+  const int n_cur = bp.n_cur[w];
+  SampState st;
+  st.is_initial = n_cur == 0;
+  st.last_ts = n_cur > 0 && toks[n_cur - 1] >= p.ts_begin;
+  st.penult_ts = n_cur < 2 || toks[n_cur - 2] >= p.ts_begin;
+  st.last_seen = -1;
+  for (int i = n_cur - 1; i >= 0; --i) if (toks[i] >= p.ts_begin) { st.last_seen = toks[i]; break; }
+  st.suppress_eot = 0;
+  float v[BEAM_PER_THREAD];
+  float lmax = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < BEAM_PER_THREAD; ++u) {
+    const int i = tid + u * BEAM_THREADS;
+    float x = -INFINITY;
+    if (i < p.n_vocab) {
+      x = lg[i] + (p.bias ? p.bias[i] : 0.f);
+      if (!sp_allowed(p, st, i)) x = -INFINITY;
+    }
+    v[u] = x;
+    lmax = fmaxf(lmax, x);
+  }
+  auto block_max = [&](float x) {
+    x = wave_max(x);
+    if ((tid & 63) == 0) red_v[tid >> 6] = x;
+    __syncthreads();
+    float r = red_v[0];
+    for (int k = 1; k < BEAM_THREADS / 64; ++k) r = fmaxf(r, red_v[k]);
+    __syncthreads();
+    return r;
+  };
+  auto block_sum = [&](float x) {
+    x = wave_sum(x);
+    if ((tid & 63) == 0) red_v[tid >> 6] = x;
+    __syncthreads();
+    float r = 0.f;
+    for (int k = 0; k < BEAM_THREADS / 64; ++k) r += red_v[k];
+    __syncthreads();
+    return r;
+  };
+  const float m = block_max(lmax);
+  float s_all = 0.f, s_ts = 0.f, t_max = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < BEAM_PER_THREAD; ++u) {
+    const int i = tid + u * BEAM_THREADS;
+    if (v[u] > -INFINITY) {
+      const float e = expf(v[u] - m);
+      s_all += e;
+      if (i >= p.ts_begin) s_ts += e; else t_max = fmaxf(t_max, v[u]);
+    }
+  }
+  const float sum_all = block_sum(s_all), sum_ts = block_sum(s_ts), text_max = block_max(t_max);
+  const float lse = m + logf(sum_all);
+  // the timestamp-mass rule: when the timestamps together outweigh every text token, only timestamps remain
+  const bool force_ts = !p.no_timestamps && sum_ts > 0.f && (m + logf(sum_ts) - lse) > (text_max - lse);
+  if (force_ts) {
+#pragma unroll
+    for (int u = 0; u < BEAM_PER_THREAD; ++u) if (tid + u * BEAM_THREADS < p.ts_begin) v[u] = -INFINITY;
+  }
+  // K + 1 rounds of arg-max; a picked token is struck out
+  for (int c = 0; c <= bp.K; ++c) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < BEAM_PER_THREAD; ++u) {
+      const int i = tid + u * BEAM_THREADS;
+      if (v[u] > bv || (v[u] == bv && v[u] > -INFINITY && i < bi)) { bv = v[u]; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float rv = red_v[0]; int ri = red_i[0];
+      for (int k = 1; k < BEAM_THREADS / 64; ++k) if (red_v[k] > rv || (red_v[k] == rv && red_i[k] < ri)) { rv = red_v[k]; ri = red_i[k]; }
+      bp.cand_lp[(int64_t)row * (bp.K + 1) + c] = rv > -INFINITY ? rv - lse : -INFINITY;
+      bp.cand_tok[(int64_t)row * (bp.K + 1) + c] = rv > -INFINITY ? ri : -1;
+      sh_pick = rv > -INFINITY ? ri : -1;
+    }
+    __syncthreads();
+    const int pick = sh_pick;
+#pragma unroll
+    for (int u = 0; u < BEAM_PER_THREAD; ++u) if (tid + u * BEAM_THREADS == pick) v[u] = -INFINITY;
+    __syncthreads();
+  }
+  (void)sh_m; (void)sh_lse; (void)sh_tsm; (void)sh_txt;
+}
+
+// one workgroup per window: rank the candidates, retire finished sequences, reorder the beams
+__global__ __launch_bounds__(256) void beam_update_kernel(SamplerParams p, BeamParams bp, int first) {
+  constexpr int MAXK = 5, MAXC = MAXK * (MAXK + 1);
+  __shared__ int s_src[MAXK], s_tok[MAXK], s_nfin, s_fin_src[MAXC], s_fin_slot[MAXC];
+  __shared__ float s_sum[MAXK], s_fin_sum[MAXC];
+  __shared__ int s_done;
+  const int w = blockIdx.x, tid = threadIdx.x, K = bp.K;
+  if (bp.win_done[w]) return;
+  const int n_cur = bp.n_cur[w];
+  const int P = bp.n_past_w[w];          // position the step that just ran wrote (prompt pass: n_prompt - 1)
+  if (tid == 0) {
+    float sc[MAXC]; int src[MAXC], tok[MAXC], ord[MAXC];
+    int nc = 0;
+    const int nb = first ? 1 : K;        // first step: the K beams are identical - only beam 0 proposes
+    for (int j = 0; j < nb; ++j) {
+      const int r = w * K + j;
+      for (int c = 0; c <= K; ++c) {
+        const int t = bp.cand_tok[(int64_t)r * (K + 1) + c];
+        if (t < 0) continue;
+        sc[nc] = (first ? 0.f : bp.beam_sum[r]) + bp.cand_lp[(int64_t)r * (K + 1) + c];
+        src[nc] = j; tok[nc] = t; ord[nc] = nc; ++nc;
+      }
+    }
+    // stable insertion sort by score, descending (ties: the earlier beam, then the more likely token)
+    for (int a = 1; a < nc; ++a) {
+      const int o = ord[a]; int b2 = a - 1;
+      while (b2 >= 0 && sc[ord[b2]] < sc[o]) { ord[b2 + 1] = ord[b2]; --b2; }
+      ord[b2 + 1] = o;
+    }
+    int saved = 0, nfin = 0, fin_cnt = bp.fin_cnt[w];
+    for (int a = 0; a < nc && saved < K; ++a) {
+      const int o = ord[a];
+      if (tok[o] == p.eot) {
+        // newly finished, best first; the pool takes them while it has room (max_candidates = beam size)
+        if (fin_cnt < K) { s_fin_src[nfin] = src[o]; s_fin_sum[nfin] = sc[o]; s_fin_slot[nfin] = fin_cnt; ++nfin; ++fin_cnt; }
+      } else {
+        s_src[saved] = src[o]; s_tok[saved] = tok[o]; s_sum[saved] = sc[o]; ++saved;
+      }
+    }
+    // fewer live continuations than beams (everything else was end-of-text or forbidden): repeat the last one
+    for (int j = saved; j < K; ++j) { s_src[j] = saved ? s_src[saved - 1] : 0; s_tok[j] = saved ? s_tok[saved - 1] : p.eot; s_sum[j] = saved ? -INFINITY : -INFINITY; }
+    s_nfin = nfin;
+    bp.fin_cnt[w] = fin_cnt;
+    const bool full = fin_cnt >= K;
+    const bool out_of_room = n_cur + 1 >= p.n_max || n_cur + 1 >= p.max_tokens || P + 2 >= p.n_text_ctx || saved == 0;
+    s_done = (full || out_of_room) ? 1 : 0;
+  }
+  __syncthreads();
+  // finished sequences: the source beam's tokens (end-of-text itself is not stored)
+  for (int f = 0; f < s_nfin; ++f) {
+    const int32_t* from = p.tokens + (int64_t)(w * K + s_fin_src[f]) * p.max_tokens;
+    int32_t* to = bp.fin_tok + ((int64_t)w * K + s_fin_slot[f]) * p.max_tokens;
+    for (int i = tid; i < n_cur; i += 256) to[i] = from[i];
+    if (tid == 0) { bp.fin_len[w * K + s_fin_slot[f]] = n_cur; bp.fin_sum[w * K + s_fin_slot[f]] = s_fin_sum[f]; }
+  }
+  // new beams: history and kv_slot rows are gathered from the source beams into the other half of the double buffers
+  for (int j = 0; j < K; ++j) {
+    const int r = w * K + j, rs = w * K + s_src[j];
+    const int32_t* from = p.tokens + (int64_t)rs * p.max_tokens;
+    int32_t* to = bp.tokens_next + (int64_t)r * p.max_tokens;
+    for (int i = tid; i < n_cur; i += 256) to[i] = from[i];
+    const int32_t* sf = bp.kv_slot + (int64_t)rs * p.n_text_ctx;
+    int32_t* stt = bp.kv_slot_next + (int64_t)r * p.n_text_ctx;
+    for (int i = tid; i <= P; i += 256) stt[i] = first ? w : sf[i];      // after the prompt pass every position lives in slot w
+    if (tid == 0) {
+      to[n_cur] = s_tok[j];
+      stt[P + 1] = r;                     // the next step writes position P + 1 of this beam into its own row
+      bp.beam_sum[r] = s_sum[j];
+      p.next_tok[r] = s_tok[j];
+      p.n_past[r] = P + 1;
+    }
+  }
+  if (tid == 0) {
+    bp.n_cur[w] = n_cur + 1;
+    bp.n_past_w[w] = P + 1;
+    if (s_done) { bp.win_done[w] = 1; atomicAdd(p.n_done, 1); }
+  }
+}
+
+void launch_beam_step(const SamplerParams& p, const BeamParams& bp, int n_windows, int first, hipStream_t s) {
+  if (bp.K < 2 || bp.K > 5) throw Error(OHW_E_INVALID_ARG, "beam search: beam size must be in 2..5");
+  if (p.n_vocab > BEAM_THREADS * BEAM_PER_THREAD) throw Error(OHW_E_INVALID_ARG, "beam search: vocabulary too large");
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(first ? n_windows : n_windows * bp.K), dim3(BEAM_THREADS), 0, s, p, bp, first);
+  hipLaunchKernelGGL(beam_update_kernel, dim3(n_windows), dim3(256), 0, s, p, bp, first);
+  HIP_CHECK(hipGetLastError());
+}
+
 #define INST(T) \
   template void launch_dec_gemm<T>(const DecGemmParams&, int, hipStream_t); \
   template void launch_embed<T>(const void*, const float*, const int32_t*, const int32_t*, float*, void*, float*, int, int, int, hipStream_t); \
-  template void launch_self_attn<T>(const void*, const void*, const void*, const int32_t*, void*, int, int, int, int, hipStream_t); \
-  template void launch_cross_attn<T>(const void*, const void*, const void*, void*, int, int, int, int, float*, unsigned*, int, const int32_t*, hipStream_t);
+  template void launch_self_attn<T>(const void*, const void*, const void*, const int32_t*, void*, int, int, int, int, hipStream_t, const int32_t*); \
+  template void launch_cross_attn<T>(const void*, const void*, const void*, void*, int, int, int, int, float*, unsigned*, int, const int32_t*, hipStream_t, int);
 INST(bf16_t)
 INST(f16_t)
 #undef INST

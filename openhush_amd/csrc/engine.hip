@@ -97,6 +97,10 @@ struct ohw_state {
   DevBuf xa_part, xa_ticket;       // cross-attention over key slices (small batches)
   int xa_rows = 0;
   DevBuf step_tok, n_past, tokens, n_cur, next_tok, done, n_done, sum_lp;
+  // beam search (made on first use): candidates, cumulative scores, the kv_slot / token-history double buffers, finished pool
+  DevBuf bm_cand_lp, bm_cand_tok, bm_sum, bm_slot[2], bm_tok2, bm_ncur, bm_npast, bm_done, bm_fin_cnt, bm_fin_tok, bm_fin_len, bm_fin_sum;
+  struct BeamGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int windows = 0, K = 0, parity = 0; SamplerParams spar{}; };
+  std::vector<BeamGraph> beam_graphs;
   DevBuf tok_lp, nosp_prob;        // per-token log-probabilities [B][max_tokens + 1], no-speech probability [B]
   DevBuf logit_bias;               // optional f32 [n_vocab] (ohw_state_set_logit_bias)
   std::vector<float> bias_host;    // the same on the host: the temperature ladder samples there (host_engine.cpp)
@@ -283,8 +287,11 @@ void run_encode(ohw_state* st, int B) {
 }
 
 // one decoder pass over M = B * n_new rows; tokens in tok_src (default st->step_tok), positions from st->n_past
+// kv_group > 1 (beam search): B rows are kv_group beams per window - cross K/V is per window, self K/V goes through kv_slot,
+// win_done flags whole windows
 template <typename T>
-void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = nullptr) {
+void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = nullptr, int kv_group = 1, const int32_t* kv_slot = nullptr,
+                      const int32_t* win_done = nullptr) {
   const ohw_ctx* c = st->ctx;
   const ohw_hparams& hp = c->hp;
   hipStream_t s = st->stream;
@@ -296,7 +303,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
   launch_embed<T>(c->emb.p, c->dec_pos.as<float>(), tok_src ? tok_src : st->step_tok.as<int32_t>(), n_past, st->dx.as<float>(),
                   pn ? st->dx16.p : nullptr, pn ? st->xstat.as<float>() : nullptr, M, n_new, d, s);
   const int64_t kv_layer = (int64_t)st->max_batch * H * C * 64;      // elements per K (or V) cache of one layer
-  const int64_t xkv_slab = (int64_t)B * H * Tn * 64;                 // cross K/V slab (batch of the last encode)
+  const int64_t xkv_slab = (int64_t)(B / kv_group) * H * Tn * 64;    // cross K/V slab (batch of the last encode)
   auto gemm = [&](const void* x, const LayerNormW* ln, const DevBuf& w, const DevBuf& bias, void* out, int N, int K, int epi, int64_t ld,
                   const DevBuf* wsum = nullptr) {
     DecGemmParams p{};
@@ -335,17 +342,17 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
       ProfScope ps(st, OHW_PROF_DEC_GEMM_QKV, 2.0 * (3.0 * d * d));
       launch_dec_gemm<T>(p, DEPI_QKV, s);
     }
-    launch_self_attn<T>(st->dq.p, kc, vc, n_past, st->da.p, M, n_new, H, C, s);
+    launch_self_attn<T>(st->dq.p, kc, vc, n_past, st->da.p, M, n_new, H, C, s, kv_slot);
     gemm(st->da.p, nullptr, w.wo, w.bo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
     gemm(st->dx.p, &w.lnx, w.wxq, w.bxq, st->dq.p, d, d, DEPI_BIAS_T, d, &w.sxq);
     {
       // algorithmic bytes: K and V of every (query row, head); the prompt pass streams them once per (window, head)
       // for all its rows (cross_attn_rows_kernel: same condition as launch_cross_attn)
       const bool rows_path = n_new >= 2 && n_new <= 4 && (int64_t)B * H >= 256;
-      ProfScope psx(st, OHW_PROF_DEC_XATTN, 2.0 * 2.0 * (double)(rows_path ? B : M) * H * Tn * 64.0);
+      ProfScope psx(st, OHW_PROF_DEC_XATTN, 2.0 * 2.0 * (double)(kv_group > 1 ? B / kv_group : rows_path ? B : M) * H * Tn * 64.0);
       launch_cross_attn<T>(st->dq.p, (const T*)st->xkv.p + (int64_t)(2 * l) * xkv_slab, (const T*)st->xkv.p + (int64_t)(2 * l + 1) * xkv_slab,
                            st->da.p, M, n_new, H, Tn, st->xa_part.as<float>(), st->xa_ticket.as<unsigned>(), st->xa_rows,
-                           st->skip_done ? st->done.as<int32_t>() : nullptr, s);
+                           kv_group > 1 ? win_done : (st->skip_done ? st->done.as<int32_t>() : nullptr), s, kv_group);
     }
     gemm(st->da.p, nullptr, w.wxo, w.bxo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
     gemm(st->dx.p, &w.ln2, w.w1, w.b1, st->df.p, 4 * d, d, DEPI_BIAS_GELU_T, 4 * d, &w.s1);
@@ -459,6 +466,10 @@ void ohw_state_free(ohw_state* st) {
   for (auto& e : st->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : st->prof_ev) if (e) (void)hipEventDestroy(e);
   for (auto& g : st->step_graphs) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+  }
+  for (auto& g : st->beam_graphs) {
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (g.graph) (void)hipGraphDestroy(g.graph);
   }
@@ -786,6 +797,163 @@ int ohw_greedy(ohw_state* st, const ohw_sample_params* sp, int batch, int32_t* t
   ohw_greedy_result r{};
   r.tokens = tokens_out; r.n_tokens = n_tokens_out; r.sum_logprob = sum_logprob_out;
   return ohw_greedy_ex(st, sp, batch, max_tokens, &r);
+}
+
+int ohw_beam_search(ohw_state* st, const ohw_sample_params* sp, int n_windows, int beam_size, int max_tokens, const ohw_beam_result* res) {
+  return guard([&] {
+    if (!st || !sp || !res || !res->tokens || !res->n_tokens) throw Error(OHW_E_INVALID_ARG, "null argument");
+    const int W = n_windows, K = beam_size, R = W * K;
+    if (W < 1 || W != st->enc_batch) throw Error(OHW_E_INVALID_ARG, "beam search: n_windows must equal the batch of the last ohw_encode");
+    if (K < 2 || K > 5) throw Error(OHW_E_INVALID_ARG, "beam search: beam_size must be in 2..5");
+    if (R > st->max_batch) throw Error(OHW_E_INVALID_ARG, "beam search: the state needs max_batch >= n_windows * beam_size decoder rows");
+    const ohw_ctx* c = st->ctx;
+    if (sp->lang_id < 0 || sp->lang_id >= c->tok.n_langs) throw Error(OHW_E_INVALID_ARG, "beam search: lang_id out of range");
+    if (sp->force_len > 0) throw Error(OHW_E_INVALID_ARG, "beam search: force_len is a greedy-only knob");
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = st->stream;
+    const int MT = st->max_tokens, C = c->hp.n_text_ctx, MB = st->max_batch;
+    if (!st->bm_sum.p) {
+      st->bm_cand_lp.alloc((size_t)MB * 6 * 4); st->bm_cand_tok.alloc((size_t)MB * 6 * 4); st->bm_sum.alloc((size_t)MB * 4, true);
+      st->bm_slot[0].alloc((size_t)MB * C * 4, true); st->bm_slot[1].alloc((size_t)MB * C * 4, true); st->bm_tok2.alloc((size_t)MB * MT * 4, true);
+      st->bm_ncur.alloc((size_t)MB * 4, true); st->bm_npast.alloc((size_t)MB * 4, true); st->bm_done.alloc((size_t)MB * 4, true);
+      st->bm_fin_cnt.alloc((size_t)MB * 4, true); st->bm_fin_tok.alloc((size_t)MB * MT * 4, true); st->bm_fin_len.alloc((size_t)MB * 4, true);
+      st->bm_fin_sum.alloc((size_t)MB * 4, true);
+    }
+    int32_t prompt[8];
+    const int n_prompt = build_prompt(c, sp, prompt);
+    const int n_max = std::min(std::min(sp->n_max, MT), C - n_prompt);
+    if (n_max < 1) throw Error(OHW_E_INVALID_ARG, "beam search: n_max < 1");
+    std::vector<int32_t> ptoks((size_t)W * n_prompt), np0((size_t)W, n_prompt - 1);
+    for (int w = 0; w < W; ++w) std::memcpy(&ptoks[(size_t)w * n_prompt], prompt, (size_t)n_prompt * 4);
+    HIP_CHECK(hipEventRecord(st->ev[4], s));
+    HIP_CHECK(hipMemcpyAsync(st->step_tok.p, ptoks.data(), ptoks.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemsetAsync(st->n_past.p, 0, (size_t)MB * 4, s));
+    HIP_CHECK(hipMemsetAsync(st->n_done.p, 0, 16, s));
+    for (DevBuf* b : {&st->bm_sum, &st->bm_ncur, &st->bm_done, &st->bm_fin_cnt, &st->bm_fin_len}) HIP_CHECK(hipMemsetAsync(b->p, 0, (size_t)MB * 4, s));
+    HIP_CHECK(hipMemcpyAsync(st->bm_npast.p, np0.data(), np0.size() * 4, hipMemcpyHostToDevice, s));
+    ohw_sample_params eff = *sp;
+    eff.n_max = n_max;
+    SamplerParams base;
+    fill_sampler(st, &eff, R, &base);
+    int32_t* tokbuf[2] = {st->tokens.as<int32_t>(), st->bm_tok2.as<int32_t>()};
+    auto params = [&](int q, SamplerParams* p, BeamParams* bp) {
+      *p = base;
+      p->tokens = tokbuf[q];
+      *bp = BeamParams{};
+      bp->K = K; bp->cand_lp = st->bm_cand_lp.as<float>(); bp->cand_tok = st->bm_cand_tok.as<int32_t>(); bp->beam_sum = st->bm_sum.as<float>();
+      bp->kv_slot = st->bm_slot[q].as<int32_t>(); bp->kv_slot_next = st->bm_slot[q ^ 1].as<int32_t>(); bp->tokens_next = tokbuf[q ^ 1];
+      bp->n_cur = st->bm_ncur.as<int32_t>(); bp->n_past_w = st->bm_npast.as<int32_t>(); bp->win_done = st->bm_done.as<int32_t>();
+      bp->fin_cnt = st->bm_fin_cnt.as<int32_t>(); bp->fin_tok = st->bm_fin_tok.as<int32_t>(); bp->fin_len = st->bm_fin_len.as<int32_t>();
+      bp->fin_sum = st->bm_fin_sum.as<float>();
+    };
+    int steps = 0, last_q = 1;
+    Dispatch::run(c->dtype, [&](auto* tag) {
+      using T = std::remove_pointer_t<decltype(tag)>;
+      run_decoder_step<T>(st, W, n_prompt);                       // the prompt once per window; its K/V stays in cache rows 0 .. W-1
+      HIP_CHECK(hipStreamSynchronize(s));                         // ptoks / np0 are stack-lifetime sources
+      ++steps;
+      SamplerParams p0; BeamParams b0;
+      params(0, &p0, &b0);
+      launch_beam_step(p0, b0, W, 1, s);                          // first candidates from the prompt's logits; writes side 1
+      // one beam iteration = {decoder step of the W * K rows, top-k per row, update per window}; the token-history and
+      // kv_slot double buffers alternate, so TWO graphs are captured (odd and even steps) and replayed in turn
+      const bool use_graph = st->graphs_enabled && st->prof_class == 0 && s != nullptr;
+      hipGraphExec_t exec[2] = {nullptr, nullptr};
+      for (int q = 0; q < 2 && use_graph; ++q) {
+        SamplerParams pq; BeamParams bq;
+        params(q, &pq, &bq);
+        for (auto& g : st->beam_graphs)
+          if (g.windows == W && g.K == K && g.parity == q && std::memcmp(&g.spar, &pq, sizeof pq) == 0) exec[q] = g.exec;
+        if (exec[q]) continue;
+        ohw_state::BeamGraph ng;
+        hipStream_t cap = st->own_stream;
+        CaptureGate gate;
+        struct StreamSwap { ohw_state* st; hipStream_t keep; ~StreamSwap() { st->stream = keep; } } swap{st, st->stream};
+        st->stream = cap;
+        HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
+        try {
+          run_decoder_step<T>(st, R, 1, st->next_tok.as<int32_t>(), K, bq.kv_slot, bq.win_done);
+          launch_beam_step(pq, bq, W, 0, cap);
+        } catch (...) {
+          hipGraph_t g = nullptr;
+          (void)hipStreamEndCapture(cap, &g);
+          if (g) (void)hipGraphDestroy(g);
+          throw;
+        }
+        HIP_CHECK(hipStreamEndCapture(cap, &ng.graph));
+        hipError_t ie = hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) { (void)hipGraphDestroy(ng.graph); HIP_CHECK(ie); }
+        ng.windows = W; ng.K = K; ng.parity = q; ng.spar = pq;
+        if (st->beam_graphs.size() >= 8) {
+          auto& g = st->beam_graphs.front();
+          if (g.exec) (void)hipGraphExecDestroy(g.exec);
+          if (g.graph) (void)hipGraphDestroy(g.graph);
+          st->beam_graphs.erase(st->beam_graphs.begin());
+        }
+        st->beam_graphs.push_back(ng);
+        exec[q] = ng.exec;
+      }
+      int32_t n_done_host = 0;
+      for (int it = 1; it < n_max; ++it) {
+        const int q = it & 1;
+        if (use_graph) {
+          HIP_CHECK(hipGraphLaunch(exec[q], s));
+        } else {
+          SamplerParams pq; BeamParams bq;
+          params(q, &pq, &bq);
+          run_decoder_step<T>(st, R, 1, st->next_tok.as<int32_t>(), K, bq.kv_slot, bq.win_done);
+          launch_beam_step(pq, bq, W, 0, s);
+        }
+        ++steps;
+        last_q = q ^ 1;
+        if ((it & 7) == 7) {
+          HIP_CHECK(hipMemcpyAsync(&n_done_host, st->n_done.p, 4, hipMemcpyDeviceToHost, s));
+          HIP_CHECK(hipStreamSynchronize(s));
+          if (n_done_host >= W) break;
+        }
+      }
+    });
+    HIP_CHECK(hipEventRecord(st->ev[5], s));
+    // read the finished pools and the live beams back; rank on the host: cumulative log-probability / length
+    std::vector<int32_t> fin_cnt((size_t)W), fin_len((size_t)R), fin_tok((size_t)R * MT), live_tok((size_t)R * MT), ncur((size_t)W);
+    std::vector<float> fin_sum((size_t)R), live_sum((size_t)R);
+    HIP_CHECK(hipMemcpyAsync(fin_cnt.data(), st->bm_fin_cnt.p, (size_t)W * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(fin_len.data(), st->bm_fin_len.p, (size_t)R * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(fin_sum.data(), st->bm_fin_sum.p, (size_t)R * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(fin_tok.data(), st->bm_fin_tok.p, (size_t)R * MT * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(live_tok.data(), tokbuf[last_q], (size_t)R * MT * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(live_sum.data(), st->bm_sum.p, (size_t)R * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(ncur.data(), st->bm_ncur.p, (size_t)W * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int w = 0; w < W; ++w) {
+      struct Cand { const int32_t* t; int n; float sum; };
+      std::vector<Cand> cands;
+      for (int f = 0; f < fin_cnt[(size_t)w]; ++f) cands.push_back({&fin_tok[(size_t)(w * K + f) * MT], fin_len[(size_t)(w * K + f)], fin_sum[(size_t)(w * K + f)]});
+      if ((int)cands.size() < K) {
+        // not enough finished sequences: the live beams join, most likely first (the published decoder's finalize())
+        std::vector<int> order((size_t)K);
+        for (int j = 0; j < K; ++j) order[(size_t)j] = j;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return live_sum[(size_t)(w * K + a)] > live_sum[(size_t)(w * K + b)]; });
+        for (int j : order) {
+          if ((int)cands.size() >= K) break;
+          if (!(live_sum[(size_t)(w * K + j)] > -INFINITY)) continue;
+          cands.push_back({&live_tok[(size_t)(w * K + j) * MT], ncur[(size_t)w], live_sum[(size_t)(w * K + j)]});
+        }
+      }
+      int best = -1;
+      float best_score = -INFINITY;
+      for (size_t i = 0; i < cands.size(); ++i) {
+        const float score = cands[i].sum / (float)std::max(1, cands[i].n);
+        if (best < 0 || score > best_score) { best = (int)i; best_score = score; }
+      }
+      const int n = best >= 0 ? std::min(cands[(size_t)best].n, max_tokens) : 0;
+      res->n_tokens[w] = n;
+      if (n) std::memcpy(res->tokens + (size_t)w * max_tokens, cands[(size_t)best].t, (size_t)n * 4);
+      if (res->sum_logprob) res->sum_logprob[w] = best >= 0 ? cands[(size_t)best].sum : 0.f;
+      if (res->n_finished) res->n_finished[w] = fin_cnt[(size_t)w];
+    }
+    st->last.decode_steps = steps;
+  });
 }
 
 int ohw_state_set_logit_bias(ohw_state* st, const float* bias, int n) {

@@ -85,15 +85,17 @@ template <typename T> void launch_dec_gemm(const DecGemmParams& p, int epilogue,
 template <typename T> void launch_embed(const void* emb_tiled, const float* pos, const int32_t* tok, const int32_t* n_past,
                                         float* x, void* x16, float* stat, int M, int n_new, int d, hipStream_t s);
 // causal self-attention of the new tokens against the cache.  q T [M][d] -> out T, activation-tile order
+// kv_slot (beam search, else null): i32 [rows][n_ctx], the cache row that holds position j of a row's sequence
 template <typename T> void launch_self_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* n_past,
-                                            void* out, int M, int n_new, int n_head, int n_ctx, hipStream_t s);
+                                            void* out, int M, int n_new, int n_head, int n_ctx, hipStream_t s, const int32_t* kv_slot = nullptr);
 // cross-attention: q T [M][d]; cross K/V head-major T [B][H][t_len][64] of this layer -> out T, activation-tile order
 // partials / tickets (may be null): scratch for cutting the keys of a (row, head) over up to XA_MAX_SPLIT workgroups when
 // M <= max_split_rows leaves most CUs idle: f32 [max_split_rows][n_head][XA_MAX_SPLIT][68], u32 [max_split_rows][n_head] (zero)
 constexpr int XA_MAX_SPLIT = 8;
 template <typename T> void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out, int M, int n_new,
                                              int n_head, int t_len, float* partials, unsigned* tickets, int max_split_rows,
-                                             const int32_t* done /* [B] or null: windows whose rows are skipped */, hipStream_t s);
+                                             const int32_t* done /* [B] or null: windows whose rows are skipped */, hipStream_t s,
+                                             int kv_group = 1 /* beam search: consecutive rows that share one window's K/V */);
 
 // device-side logits filter + arg-max (restates oracle ref_process_logits)
 struct SamplerParams {
@@ -118,6 +120,24 @@ struct SamplerParams {
                          //   to slot n_cur without being counted (whisper.cpp sums it into avg_logprobs), or null
   float* nosp_prob;      // [batch] softmax probability of the no-speech token in the window's first, unfiltered row, or null
 };
+// beam search state of a batch of windows (decode.hip): beam j of window w is decoder row w * K + j
+struct BeamParams {
+  int32_t K;              // beam size, 2..5
+  float* cand_lp;         // [rows][K + 1] log-probabilities of every row's best next tokens
+  int32_t* cand_tok;      // [rows][K + 1]
+  float* beam_sum;        // [rows] cumulative log-probability
+  int32_t* kv_slot;       // [rows][n_text_ctx] self-K/V row per position (this step's view)
+  int32_t* kv_slot_next;  // the other half of the double buffer (written by the update, read by the next step)
+  int32_t* tokens_next;   // [rows][max_tokens] the other half of the token-history double buffer
+  int32_t* n_cur;         // [windows] tokens sampled so far
+  int32_t* n_past_w;      // [windows] position written by the step that just ran
+  int32_t* win_done;      // [windows]
+  int32_t* fin_cnt;       // [windows] finished sequences in the pool (at most K)
+  int32_t* fin_tok;       // [windows][K][max_tokens]
+  int32_t* fin_len;       // [windows][K]
+  float* fin_sum;         // [windows][K] cumulative log-probability, the end-of-text token's included
+};
+void launch_beam_step(const SamplerParams& p, const BeamParams& bp, int n_windows, int first, hipStream_t s);
 constexpr int SAMPLER_SPLIT = 8;
 constexpr int SAMPLER_PART_WORDS = 12;
 void launch_sampler(const SamplerParams& p, hipStream_t s);

@@ -88,6 +88,11 @@ class VadEngineC(C.Structure):
     _fields_ = [("user", C.c_void_p), ("process", VAD_PROCESS_FN), ("reset", VAD_RESET_FN), ("chunk_size", C.c_int32), ("sample_rate", C.c_uint32)]
 
 
+class BeamResult(C.Structure):
+    _fields_ = [("tokens", C.POINTER(C.c_int32)), ("n_tokens", C.POINTER(C.c_int32)), ("sum_logprob", C.POINTER(C.c_float)),
+                ("n_finished", C.POINTER(C.c_int32))]
+
+
 class WindowQuality(C.Structure):
     _fields_ = [("n_tokens", C.c_int32), ("avg_logprob", C.c_float), ("entropy", C.c_float), ("would_fallback", C.c_int32),
                 ("temperature", C.c_float), ("no_speech_prob", C.c_float), ("no_speech", C.c_int32), ("seek_delta", C.c_int32),
@@ -120,7 +125,7 @@ EXPORTS = [
     "ohw_greedy_ex", "ohw_state_set_logit_bias", "ohw_dbg_sample",
     "ohw_decode_active", "ohw_rng_new", "ohw_rng_free", "ohw_sample_host", "ohw_default_decode_policy", "ohw_engine_set_decode_policy",
     "ohw_engine_last_trace", "ohw_engine_set_schedule", "ohw_ctx_dtype",
-    "ohw_dsp_resample_sinc", "ohw_default_vad_config", "ohw_vad_state_new", "ohw_vad_state_free", "ohw_vad_state_update",
+    "ohw_beam_search", "ohw_dsp_resample_sinc", "ohw_default_vad_config", "ohw_vad_state_new", "ohw_vad_state_free", "ohw_vad_state_update",
     "ohw_vad_state_is_speech", "ohw_vad_state_speech_start", "ohw_vad_state_reset", "ohw_vad_energy_engine", "ohw_vad_energy_engine_free",
     "ohw_vad_run",
     "ohw_pool_create", "ohw_pool_transcribe", "ohw_pool_last_text", "ohw_pool_last_tokens", "ohw_pool_last_quality",
@@ -236,6 +241,7 @@ def lib():
         L.ohw_greedy.argtypes = [vp, C.POINTER(SampleParams), C.c_int, ip, ip, C.c_int, fp]
         L.ohw_greedy_ex.argtypes = [vp, C.POINTER(SampleParams), C.c_int, C.c_int, C.POINTER(GreedyResult)]
         L.ohw_state_set_logit_bias.argtypes = [vp, fp, C.c_int]
+        L.ohw_beam_search.argtypes = [vp, C.POINTER(SampleParams), C.c_int, C.c_int, C.c_int, C.POINTER(BeamResult)]
         L.ohw_dbg_sample.argtypes = [vp, C.POINTER(SampleParams), fp, ip, C.c_int, ip, C.c_int, ip, fp, fp]
         L.ohw_decode_active.argtypes = [vp, ip, C.c_int, ip, C.c_int, ip, fp]
         L.ohw_rng_new.argtypes = [C.c_uint32]
@@ -559,6 +565,19 @@ class State:
         _check(lib().ohw_greedy_ex(self.h, C.byref(p), batch, cap, C.byref(r)))
         return [{"tokens": [int(x) for x in toks[b, :nt[b]]], "logprobs": lps[b, :nt[b] + (1 if eot[b] else 0)].copy(),
                  "ended_by_eot": bool(eot[b]), "no_speech_prob": float(nsp[b]), "sum_logprob": float(slp[b])} for b in range(batch)]
+
+    def beam_search(self, n_windows: int, beam_size: int = 5, p: Optional[SampleParams] = None):
+        """ohw_beam_search for the windows of the last encode -> [dict(tokens, sum_logprob, n_finished)]; the state needs
+        max_batch >= n_windows * beam_size"""
+        p = p or self.ctx.default_params()
+        cap = self.ctx.hp.n_text_ctx
+        toks = np.zeros((n_windows, cap), dtype=np.int32)
+        nt = np.zeros(n_windows, dtype=np.int32)
+        sm = np.zeros(n_windows, dtype=np.float32)
+        nf = np.zeros(n_windows, dtype=np.int32)
+        r = BeamResult(_ip(toks), _ip(nt), _fp(sm), _ip(nf))
+        _check(lib().ohw_beam_search(self.h, C.byref(p), n_windows, beam_size, cap, C.byref(r)))
+        return [{"tokens": [int(x) for x in toks[w, :nt[w]]], "sum_logprob": float(sm[w]), "n_finished": int(nf[w])} for w in range(n_windows)]
 
     def set_logit_bias(self, bias: Optional[np.ndarray]):
         """additive bias [n_vocab] on every logits row before the filter (None clears it)"""

@@ -125,6 +125,9 @@ def lib():
         L.ref_decode_pass.argtypes = [C.c_void_p, C.POINTER(SampleParams), fp, C.c_float, C.POINTER(MT19937), ip, C.c_int, ip, fp, ip, fp, dp, fp]
         L.ref_decode_window.argtypes = [C.c_void_p, C.POINTER(SampleParams), C.POINTER(DecodePolicy), fp, C.c_int, C.c_int, C.c_int,
                                         C.POINTER(MT19937), ip, fp, C.POINTER(WindowResult)]
+        L.ref_beam_search.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(SampleParams), fp, ip, fp, ip, ip, fp, ip, ip]
+        L.ref_score_sequence.argtypes = [C.c_void_p, C.POINTER(SampleParams), fp, ip, C.c_int, C.c_int]
+        L.ref_score_sequence.restype = C.c_float
         L.ref_num_threads.restype = C.c_int
         L.ref_set_num_threads.argtypes = [C.c_int]
         _lib = L
@@ -396,6 +399,31 @@ def _state_decode_window(self, p: SampleParams, pol: DecodePolicy, bias=None, se
     return [int(x) for x in out[:n]], res, [int(x) for x in out[:res.ev.n_sampled]]
 
 
+def beam_search(model: Model, enc: np.ndarray, p: SampleParams, beam_size: int, bias=None):
+    """the published Whisper beam search on one encoded window: dict(tokens, sum_logprob, n_finished, candidates=[(tokens, sum)])"""
+    states = [State(model) for _ in range(beam_size)]
+    for s in states:
+        s.set_encoder_output(enc)
+    arr = (C.c_void_p * beam_size)(*[s.h for s in states])
+    cap = model.n_text_ctx
+    out = np.zeros(cap, np.int32); allt = np.zeros((beam_size, cap), np.int32); alll = np.zeros(beam_size, np.int32)
+    alls = np.zeros(beam_size, np.float32)
+    sm, na, nf = C.c_float(0), C.c_int32(0), C.c_int32(0)
+    nul = C.cast(None, C.POINTER(C.c_float))
+    bp = _fp(np.ascontiguousarray(bias, dtype=np.float32)) if bias is not None else nul
+    n = lib().ref_beam_search(arr, beam_size, C.byref(p), bp, _ip(out), C.byref(sm), _ip(allt), _ip(alll), _fp(alls), C.byref(na), C.byref(nf))
+    return {"tokens": [int(x) for x in out[:n]], "sum_logprob": float(sm.value), "n_finished": int(nf.value),
+            "candidates": [([int(x) for x in allt[i, :alll[i]]], float(alls[i])) for i in range(na.value)]}
+
+
+def _state_score_sequence(self, p: SampleParams, tokens, ended: bool, bias=None) -> float:
+    t = np.asarray(list(tokens) or [0], dtype=np.int32)
+    nul = C.cast(None, C.POINTER(C.c_float))
+    bp = _fp(np.ascontiguousarray(bias, dtype=np.float32)) if bias is not None else nul
+    return float(lib().ref_score_sequence(self.h, C.byref(p), bp, _ip(t), len(tokens), int(ended)))
+
+
+State.score_sequence = _state_score_sequence
 State.decode_pass = _state_decode_pass
 State.decode_window = _state_decode_window
 

@@ -171,7 +171,7 @@ def test_config4_one_hour_120_windows_on_one_gpu(E, large_v3_file, monkeypatch):
         eng = E.WhisperEngine.new(large_v3_file, "auto", False, True, 0, E.OHW_DTYPE_BF16, 32)
         eng.set_decode_policy(temperature_inc=0.0)           # T = 0 only: the fallback ladder is a per-window host path
         eng.set_schedule(sched)
-        eng.transcribe(E.AudioBuffer(pcm[:480000 * 70], 16000))      # warm-up: states, streams, graph captures
+        eng.transcribe(E.AudioBuffer(pcm, 16000))                    # warm-up: states, streams, graph captures
         t0 = time.perf_counter()
         res = eng.transcribe(E.AudioBuffer(pcm, 16000))
         print(f"config#4 schedule {cus}: 1 h of audio in {time.perf_counter() - t0:.2f} s")

@@ -115,7 +115,9 @@ def _walk_and_compare(E, oracle, om, eng, windows_pcm, bias, pol, seeks=None, en
                 elif T == 0.0:
                     assert r["margins"][i] < 2 * TOL, (w, k, i, t, r["choice"][i], float(r["margins"][i]))
                 else:
-                    assert r["gaps"][i] < 0.02, (w, k, i, t, r["choice"][i], float(r["gaps"][i]))
+                    # a draw next to an interval edge, or a near-tie of the timestamp-mass rule (timestamps' total mass
+                    # against the best text token: it switches the whole distribution; margins[] carries it at T > 0)
+                    assert r["gaps"][i] < 0.02 or r["margins"][i] < 2 * TOL / T, (w, k, i, t, r["choice"][i], float(r["gaps"][i]), float(r["margins"][i]))
             ev = oracle.evaluate_sequence(om, toks, r["plogs"], seek, end, n_max, False, mode)
             assert ev.n_sampled == len(toks), (w, k, ev.n_sampled, len(toks))       # the engine stopped where whisper.cpp's loop exits
             again = oracle.pass_needs_fallback(ev, pol, r["no_speech_prob"], k == len(temps) - 1)
