@@ -84,24 +84,3 @@ def test_beam_search_matches_oracle(E, oracle, tmp_models, dt):
     assert exact >= 0.7 * total
     with pytest.raises(E.WhisperError):
         E.State(ctx, 4).beam_search(1, 5)              # no encode / too few decoder rows
-
-
-def test_beam_search_beats_or_equals_greedy(E, oracle, tmp_models):
-    """The defining property: the beam's winner is at least as likely per token as the greedy sequence (same filter)."""
-    path = tmp_models("micro")
-    om = oracle.Model.load(path)
-    ctx = E.Context.from_file(path, 0, E.OHW_DTYPE_F16)
-    bias = _bias(om, 6.0, 27.0)
-    pcm = np.stack([synth.synth_audio(s) for s in (3, 11)])
-    st = E.State(ctx, 10)
-    st.set_logit_bias(bias)
-    st.mel(pcm, None, E.OHW_MEL_ZERO_TAIL, want=False)
-    st.encode(2)
-    p = ctx.default_params(); p.n_max = 24
-    beams = st.beam_search(2, 5, p)
-    greedy = st.greedy_ex(2, p)
-    for w in range(2):
-        g = greedy[w]
-        g_score = float(g["logprobs"].sum()) / max(1, len(g["tokens"]))
-        b_score = beams[w]["sum_logprob"] / max(1, len(beams[w]["tokens"]))
-        assert b_score >= g_score - 1e-3, (w, b_score, g_score)
