@@ -67,7 +67,8 @@ def test_config2_small_batch1_bf16_against_oracle(E, oracle):
     enc = st.fetch("enc", 1)[0]
     err = np.abs(enc - ref_enc)
     print(f"config#2 encoder: max abs err {err.max():.4f}, mean {err.mean():.5f}")
-    assert err.max() < 0.2 and err.mean() < 0.01, (err.max(), err.mean())
+    # observed on MI355X (round 2): max 0.0273, mean 0.0039 -> tolerances at 2x observed
+    assert err.max() < 0.055 and err.mean() < 0.008, (err.max(), err.mean())
     s = oracle.State(om)
     s.set_encoder_output(ref_enc)
     # teacher-forced logits: the prompt in one call, then 6 single-token steps on the oracle's own picks
@@ -83,7 +84,7 @@ def test_config2_small_batch1_bf16_against_oracle(E, oracle):
         worst = max(worst, float(np.abs(got - ref).max()))
         tok = int(ref.argmax())
     print(f"config#2 logits: worst abs err {worst:.4f} at sigma {sig:.2f}")
-    assert worst < 0.25, (worst, sig)
+    assert worst < 0.23, (worst, sig)          # observed 0.113 - 0.116 abs at sigma 4.01
     # greedy through the device loop: the oracle walks the GPU's path and agrees at every step outside near-ties
     p = ctx.default_params(); p.n_max = 32
     g = st.greedy_ex(1, p)[0]

@@ -408,23 +408,25 @@ def test_large_v3_dims_one_window_matches_oracle(E, oracle):
     # 32 layers of bf16 GEMM operands: compare relative to the activation scale (LayerNorm output, O(1))
     err = np.abs(enc - ref_enc)
     print(f"large-v3 encoder output vs oracle: max abs err {err.max():.4f}, mean {err.mean():.5f}")
-    assert err.max() < 0.25 and err.mean() < 0.02, (err.max(), err.mean())
+    # observed on MI355X (round 2): max 0.0326, mean 0.0050 -> tolerances at 2x observed
+    assert err.max() < 0.07 and err.mean() < 0.011, (err.max(), err.mean())
     s = oracle.State(om)
     s.set_encoder_output(ref_enc)
     prompt = [ctx.tok.sot, ctx.tok.sot + 1, ctx.tok.transcribe]
     ref = s.decode(prompt, 0)
     got = st.decode(np.asarray([prompt], np.int32), [0])[0]
     sig = float(ref.std())
+    # observed: worst 0.134 - 0.140 abs at sigma 4.02 (0.035 sigma) -> tolerance 0.07 sigma = 2x observed
     worst = float(np.abs(got - ref).max())
-    assert worst < 0.12 * sig, (worst, sig)
+    assert worst < 0.07 * sig, (worst, sig)
     tok = int(ref.argmax())
     margin = float(np.sort(ref)[-1] - np.sort(ref)[-2])
-    assert int(got.argmax()) == tok or margin < 0.12 * sig
+    assert int(got.argmax()) == tok or margin < 0.14 * sig
     for i in range(3):
         ref = s.decode([tok], 3 + i)
         got = st.decode(np.asarray([[tok]], np.int32), [3 + i])[0]
         worst = max(worst, float(np.abs(got - ref).max()))
-        assert np.abs(got - ref).max() < 0.12 * sig
+        assert np.abs(got - ref).max() < 0.07 * sig
         tok = int(ref.argmax())
     print(f"large-v3 logits vs oracle: worst abs err {worst:.4f} at sigma {sig:.3f} ({worst / sig:.4f} sigma)")
     om.close()
