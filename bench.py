@@ -38,8 +38,8 @@ PROF_NAMES = {1: "gemm256_kernel (encoder / cross-KV MFMA GEMM)", 2: "encoder_at
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--tokens", type=int, default=100)
@@ -52,10 +52,13 @@ def main():
     ap.add_argument("--decoders", type=int, default=1,
                     help="with --pipeline: decodes in flight beside the front end (each on its own CU-masked stream, driven by its own "
                          "host thread): the latency-bound GEMM chain of one decode hides under the K/V stream of the other")
-    ap.add_argument("--phases", type=int, default=4,
-                    help="G > 1 (default 4, the engine's LANES schedule): the front ends of G batches run one after the other on every CU, "
-                         "then their G decodes side by side on G disjoint CU sets (one's latency-bound GEMM chain under the others' K/V "
+    ap.add_argument("--phases", type=int, default=2,
+                    help="G > 1 (default 2, the engine's LANES schedule): the front ends of G x --merge batches run one after the other on "
+                         "every CU, then G decodes side by side on G disjoint CU sets (one's latency-bound GEMM chain under the others' K/V "
                          "streams); 0 or 1: see --pipeline")
+    ap.add_argument("--merge", type=int, default=4,
+                    help="with --phases: batches decoded TOGETHER by one lane (ohw_encode_slice: their front ends feed one decode batch of "
+                         "merge x batch rows - the decoder streams its weights once per step whatever its batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=0, help="decode tokens in the CPU sample (0 = same as --tokens)")
     ap.add_argument("--cpu-windows", type=int, default=2, help="30 s windows in the CPU sample")
@@ -167,14 +170,16 @@ def main():
     pipe = None
     D = max(1, args.decoders)
     G = max(0, args.phases)
+    MG = max(1, args.merge)
     if G > 1 and S == 1:
         n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
         try:
             full = E.Stream(local_rank, 0, 0)
             dss = [E.Stream(local_rank, l * (n_cu // G), n_cu // G) for l in range(G)]
             es = ds = full
-            pst = [st] + [E.State(ctx, B) for _ in range(G - 1)]
-            pipe = {"schedule": "phases", "decoders_side_by_side": G, "decoder_cus": n_cu // G, "batches_in_flight": G}
+            pst = [E.State(ctx, B * MG) for _ in range(G)]
+            pipe = {"schedule": "lanes", "decoders_side_by_side": G, "batches_per_decode": MG, "decoder_cus": n_cu // G,
+                    "batches_in_flight": G * MG}
         except E.WhisperError as ex:
             print(f"[bench] CU-masked streams unavailable ({ex}); running one batch after the other", file=sys.stderr, flush=True)
             pipe = None
@@ -182,34 +187,47 @@ def main():
         def run_steps(n):           # noqa: F811
             out = [None] * n
             err = []
-            for g0 in range(0, n, G):
-                grp = list(range(g0, min(n, g0 + G)))
-                for j, i in enumerate(grp):
+            for g0 in range(0, n, G * MG):
+                grp = list(range(g0, min(n, g0 + G * MG)))
+                # lane j decodes steps grp[j * MG : (j + 1) * MG] as ONE batch; their front ends (B windows each) run one after the
+                # other on every CU and write their cross K/V into that lane's decode batch (ohw_encode_slice)
+                # (a short last group is dealt evenly: two half-size decodes side by side beat one full-size decode alone)
+                cnt = [len(grp) // G + (1 if j < len(grp) % G else 0) for j in range(G)]
+                lanes, at = [], 0
+                for c in cnt:
+                    if c:
+                        lanes.append(grp[at:at + c])
+                    at += c
+                for j, steps_j in enumerate(lanes):
                     s_ = pst[j]
                     s_.set_stream(full.ptr)
-                    s_.mel_device(pcm.data_ptr(), pcm.shape[1], n_samples, E.OHW_MEL_ZERO_TAIL)
-                    s_.encode(B)
-                if len(grp) == 1:
-                    out[grp[0]], _ = pst[0].greedy(B, p)
-                    continue
+                    for k in range(len(steps_j)):
+                        s_.mel_device(pcm.data_ptr(), pcm.shape[1], n_samples, E.OHW_MEL_ZERO_TAIL)
+                        s_.encode_slice(B, k * B, len(steps_j) * B)
                 dbg = os.environ.get("OHW_BENCH_DEBUG") == "1"
                 if dbg:
                     tg0 = time.perf_counter(); full.sync(); tg1 = time.perf_counter()
-                for j in range(len(grp)):
-                    dss[j].wait(full)
 
-                def lane(j, i):
+                def lane(j, steps_j):
                     try:
-                        pst[j].set_stream(dss[j].ptr)
-                        out[i], _ = pst[j].greedy(B, p)
-                        full.wait(dss[j])            # the next group's front ends start after every decode of this one
+                        toks_j, _ = pst[j].greedy(len(steps_j) * B, p)
+                        for k, i in enumerate(steps_j):
+                            out[i] = toks_j[k * B:(k + 1) * B]
                     except Exception as ex:      # noqa: BLE001
                         err.append(ex)
-                th = [threading.Thread(target=lane, args=(j, i)) for j, i in enumerate(grp)]
-                for t in th:
-                    t.start()
-                for t in th:
-                    t.join()
+                if len(lanes) == 1:
+                    lane(0, lanes[0])
+                else:
+                    for j in range(len(lanes)):
+                        dss[j].wait(full)
+                        pst[j].set_stream(dss[j].ptr)
+                    th = [threading.Thread(target=lane, args=(j, sj)) for j, sj in enumerate(lanes)]
+                    for t in th:
+                        t.start()
+                    for t in th:
+                        t.join()
+                    for j in range(len(lanes)):
+                        full.wait(dss[j])            # the next group's front ends start after every decode of this one
                 if dbg:
                     print(f"[bench] group {grp}: front ends drained after {1e3 * (tg1 - tg0):.1f} ms of waiting, decodes {1e3 * (time.perf_counter() - tg1):.1f} ms", file=sys.stderr, flush=True)
                 if err:
@@ -421,7 +439,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     # release the device objects in a defined order (states and streams before their context) rather than at interpreter exit
-    for s_ in states + (pipe and pst[1:] or []):
+    for s_ in states + [x for x in (pipe and pst or []) if x is not st]:
         s_.close()
     if pipe:
         for x in [es, full] + dss:

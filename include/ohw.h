@@ -187,6 +187,11 @@ int ohw_mel(ohw_state* st, const float* pcm, int64_t pcm_stride, const int32_t* 
             int pcm_on_device, int mel_mode, float* mel_out);
 /* encoder + cross-attention K/V of every decoder layer, for the windows of the last ohw_mel      */
 int ohw_encode(ohw_state* st, int batch);
+/* the same into windows [first, first + batch) of a decode batch of `total` windows (total <= max_batch): several front-end
+ * passes can feed ONE decode - the decoder streams its weights once per step whatever its batch, so four 32-window front ends
+ * decoded as one 128-row batch move 13 % fewer bytes per token than four 32-row decodes.  ohw_greedy / ohw_decode /
+ * ohw_beam_search then take batch = total.                                                                          */
+int ohw_encode_slice(ohw_state* st, int batch, int first, int total);
 /* feed tokens[b][0..n_new) at positions n_past[b].. and return logits of the last fed position    */
 /* per window: logits_out [batch][n_vocab] f32 (host).  tokens: [batch][n_new] row-major.          */
 int ohw_decode(ohw_state* st, const int32_t* tokens, int n_new, const int32_t* n_past, int batch, float* logits_out);
@@ -345,13 +350,15 @@ int ohw_engine_set_window_mode(ohw_engine* e, int mode);
  *   SEQUENTIAL  one batch after the other;
  *   PIPELINE    front end (mel, encoder, cross K/V) of batch i+1 on OHW_ENGINE_ENC_CUS compute units beside the decode of
  *               batch i on the rest (round 1's schedule);
- *   LANES       (default) groups of `lanes` batches: their front ends one after the other on every compute unit, then
- *               their decodes side by side, each on its own CU-masked stream and host thread - a decode alternates an
- *               HBM-bound kernel with a latency-bound chain, several of them together keep HBM busy.
+ *   LANES       (default) groups of `lanes` decode batches, each fed by up to `merge` front-end batches of max_batch windows
+ *               (ohw_encode_slice): the front ends run one after the other on every compute unit, then the decodes side
+ *               by side, each on its own CU-masked stream and host thread - a decode alternates an HBM-bound kernel with a
+ *               latency-bound chain, several of them together keep HBM busy, and a merged decode streams the weights once
+ *               for all its windows.
  * The schedule's extra states and streams are made when a long input first needs them; environment defaults:
- * OHW_ENGINE_SCHEDULE = sequential | pipeline | lanes, OHW_ENGINE_LANES (4), OHW_ENGINE_ENC_CUS (96). */
+ * OHW_ENGINE_SCHEDULE = sequential | pipeline | lanes, OHW_ENGINE_LANES (2), OHW_ENGINE_MERGE (4), OHW_ENGINE_ENC_CUS (96). */
 enum { OHW_SCHEDULE_SEQUENTIAL = 0, OHW_SCHEDULE_PIPELINE = 1, OHW_SCHEDULE_LANES = 2 };
-int ohw_engine_set_schedule(ohw_engine* e, int schedule, int lanes /* 0 = keep */);
+int ohw_engine_set_schedule(ohw_engine* e, int schedule, int lanes /* 0 = keep */, int merge /* 0 = keep */);
 /* tokens of the last transcribe, per 30 s window concatenated (for parity tests)                  */
 int ohw_engine_last_tokens(ohw_engine* e, const int32_t** tokens, int* n);
 /* WhisperEngine::benchmark(safety_margin) — reference :334-387                                    */

@@ -73,7 +73,8 @@ static int dec_ksplit_short() { return env_int("OHW_DEC_KSPLIT_SHORT", 1, 1, DEC
 struct ohw_state {
   ohw_ctx* ctx = nullptr;
   int max_batch = 0;
-  int enc_batch = 0;  // windows of the last mel / encode
+  int enc_batch = 0;  // windows of the decode batch the cross K/V holds (the last ohw_encode, or the total of its slices)
+  int mel_batch = 0;  // windows of the last ohw_mel
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   // front end
@@ -230,8 +231,9 @@ void run_mel(ohw_state* st, const float* pcm_dev, int64_t stride, int batch, int
   launch_mel<T>(p, st->stream);
 }
 
+// first / total: the cross K/V of these B windows go to windows [first, first + B) of a decode batch of `total` windows
 template <typename T>
-void run_encode(ohw_state* st, int B) {
+void run_encode(ohw_state* st, int B, int first, int total) {
   const ohw_ctx* c = st->ctx;
   const ohw_hparams& hp = c->hp;
   hipStream_t s = st->stream;
@@ -282,7 +284,7 @@ void run_encode(ohw_state* st, int B) {
   g.A = st->enc.p; g.W = c->xkv_w.p; g.bias = c->xkv_b.as<float>(); g.out = st->xkv.p;
   g.M = M; g.N = (int64_t)2 * hp.n_text_layer * hp.n_text_state; g.K = d;
   g.lda = d; g.a_batch_stride = Tn * d; g.rows_per_batch = Tn; g.ldc = 0; g.c_batch_stride = 0;
-  g.d_model = hp.n_text_state; g.n_head = hp.n_text_head; g.t_len = (int)Tn; g.batch = B;
+  g.d_model = hp.n_text_state; g.n_head = hp.n_text_head; g.t_len = (int)Tn; g.batch = total; g.batch_offset = first;
   { ProfScope ps(st, OHW_PROF_ENC_GEMM, 2.0 * g.M * g.N * g.K); launch_gemm<T>(g, EPI_CROSSKV_T, s); }
 }
 
@@ -579,6 +581,7 @@ int ohw_mel(ohw_state* st, const float* pcm, int64_t pcm_stride, const int32_t* 
       run_mel<T>(st, pcm_dev, stride, batch, mel_mode);
     });
     HIP_CHECK(hipEventRecord(st->ev[1], s));
+    st->mel_batch = batch;
     st->enc_batch = batch;
     if (mel_out) {
       HIP_CHECK(hipMemcpyAsync(mel_out, st->logmel.p, (size_t)batch * st->ctx->hp.n_mels * CHUNK_FRAMES * 4, hipMemcpyDeviceToHost, s));
@@ -587,19 +590,23 @@ int ohw_mel(ohw_state* st, const float* pcm, int64_t pcm_stride, const int32_t* 
   });
 }
 
-int ohw_encode(ohw_state* st, int batch) {
+int ohw_encode_slice(ohw_state* st, int batch, int first, int total) {
   return guard([&] {
     if (!st) throw Error(OHW_E_INVALID_ARG, "state is null");
-    if (batch < 1 || batch != st->enc_batch) throw Error(OHW_E_INVALID_ARG, "encode: batch must equal the batch of the last ohw_mel");
+    if (batch < 1 || batch != st->mel_batch) throw Error(OHW_E_INVALID_ARG, "encode: batch must equal the batch of the last ohw_mel");
+    if (first < 0 || total < first + batch || total > st->max_batch) throw Error(OHW_E_INVALID_ARG, "encode: slice exceeds the state's max_batch");
     HIP_CHECK(hipSetDevice(st->ctx->device));
     HIP_CHECK(hipEventRecord(st->ev[2], st->stream));
     Dispatch::run(st->ctx->dtype, [&](auto* tag) {
       using T = std::remove_pointer_t<decltype(tag)>;
-      run_encode<T>(st, batch);
+      run_encode<T>(st, batch, first, total);
     });
     HIP_CHECK(hipEventRecord(st->ev[3], st->stream));
+    st->enc_batch = total;
   });
 }
+
+int ohw_encode(ohw_state* st, int batch) { return ohw_encode_slice(st, batch, 0, batch); }
 
 int ohw_decode_active(ohw_state* st, const int32_t* tokens, int n_new, const int32_t* n_past, int batch, const int32_t* active,
                       float* logits_out) {

@@ -23,7 +23,8 @@ struct GemmParams {
   int64_t lda, a_batch_stride, rows_per_batch;
   int64_t ldc, c_batch_stride;  // output row m at out + (m / rows_per_batch) * c_batch_stride + (m % rows_per_batch) * ldc
   // EPI_CROSSKV_T
-  int32_t d_model, n_head, t_len, batch;
+  int32_t d_model, n_head, t_len, batch;   // batch = windows of the decode batch the K/V belong to
+  int32_t batch_offset;                    // first window of this GEMM's rows inside that decode batch (ohw_encode_slice)
   int32_t group_m;    // gemm256: m-tiles per L2-locality group (set by the launcher)
 };
 

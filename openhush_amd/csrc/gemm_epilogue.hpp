@@ -48,7 +48,7 @@ __device__ __forceinline__ void gemm_store_row(const GemmParams& p, int64_t m, i
     // n -> slab (layer*2 + k/v), head, dh ; out[slab][b][h][t][64]
     const int64_t slab = nb / p.d_model, rem = nb % p.d_model;
     const int64_t h = rem >> 6, dh = rem & 63;
-    T* o = (T*)p.out + ((((slab * p.batch + b) * p.n_head + h) * p.t_len + rr) << 6) + dh;
+    T* o = (T*)p.out + ((((slab * p.batch + b + p.batch_offset) * p.n_head + h) * p.t_len + rr) << 6) + dh;
     u32x4 lo, hi;
     lo.x = pack2<T>(v[0], v[1]); lo.y = pack2<T>(v[2], v[3]); lo.z = pack2<T>(v[4], v[5]); lo.w = pack2<T>(v[6], v[7]);
     hi.x = pack2<T>(v[8], v[9]); hi.y = pack2<T>(v[10], v[11]); hi.z = pack2<T>(v[12], v[13]); hi.w = pack2<T>(v[14], v[15]);

@@ -157,6 +157,8 @@ ohw_engine* engine_wrap_ctx(ohw_ctx* ctx, const std::string& language, bool tran
   e->device = device;
   if (const char* ev = getenv("OHW_ENGINE_ENC_CUS")) e->enc_cus = std::max(0, atoi(ev));
   if (const char* ev = getenv("OHW_ENGINE_LANES")) e->lanes = std::min(16, std::max(1, atoi(ev)));
+  if (const char* ev = getenv("OHW_ENGINE_MERGE")) e->merge = std::min(8, std::max(1, atoi(ev)));
+  if (e->max_batch * e->merge > 256) e->merge = std::max(1, 256 / e->max_batch);     // a state holds at most 256 windows
   if (const char* ev = getenv("OHW_ENGINE_SCHEDULE")) {
     const std::string v = ev;
     e->schedule = v == "sequential" ? OHW_SCHEDULE_SEQUENTIAL : v == "pipeline" ? OHW_SCHEDULE_PIPELINE : OHW_SCHEDULE_LANES;
@@ -341,20 +343,20 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
         check(ohw_encode(st, batch_of(bi)));
       };
       // the decode of one batch on whatever stream the state is set to; fills sc.runs (and sc.trace); re-entrant per Scratch
-      auto decode_batch = [&](Scratch& sc, ohw_state* st, int64_t bi, const int32_t* nsb) {
-        const int B = batch_of(bi);
+      auto decode_windows = [&](Scratch& sc, ohw_state* st, int64_t w0, int B, const int32_t* nsb) {
         std::vector<int> zero((size_t)B, 0), ends((size_t)B);
         for (int b = 0; b < B; ++b) ends[(size_t)b] = mel_frames(nsb[b]);
-        greedy_t0(sc, st, B, zero.data(), ends.data(), bi * e->max_batch);
+        greedy_t0(sc, st, B, zero.data(), ends.data(), w0);
         for (int b = 0; b < B; ++b) if (ends[(size_t)b] <= 100) { sc.runs[(size_t)b] = WindowRun(); sc.runs[(size_t)b].ev.result_len = 0; }
         bool any = false;
         for (int b = 0; b < B; ++b) any = any || sc.runs[(size_t)b].pending;
         if (any) {
           Rngs lr;
           lr.reset((size_t)B);
-          run_ladder(sc, st, B, zero.data(), ends.data(), bi * e->max_batch, lr.v);
+          run_ladder(sc, st, B, zero.data(), ends.data(), w0, lr.v);
         }
       };
+      auto decode_batch = [&](Scratch& sc, ohw_state* st, int64_t bi, const int32_t* nsb) { decode_windows(sc, st, bi * e->max_batch, batch_of(bi), nsb); };
       auto collect = [&](Scratch& sc, int B) {
         flush_trace(sc);
         for (int b = 0; b < B; ++b) emit(sc.runs[(size_t)b]);
@@ -368,40 +370,64 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
         if (hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || total < 2) rc = OHW_E_TRANSCRIBE;
         if (rc == OHW_OK && !e->s_full) rc = ohw_stream_create(e->device, 0, 0, &e->s_full);
         if (e->states.empty()) e->states.assign(1, e->state);
-        const int want_states = schedule == OHW_SCHEDULE_LANES ? (int)std::min<int64_t>(e->lanes, n_batches) : 2;
-        while (rc == OHW_OK && (int)e->states.size() < want_states) {
-          ohw_state* st = nullptr;
-          rc = ohw_state_create(e->ctx, e->max_batch, &st);
-          if (rc == OHW_OK) e->states.push_back(st);
+        // LANES: decode batches of up to merge front-end batches (ohw_encode_slice); lane states hold max_batch * merge windows
+        const int merge = std::max(1, e->merge);
+        const int64_t DBw = (int64_t)e->max_batch * merge;
+        const int64_t n_dbatches = (n_win + DBw - 1) / DBw;
+        const int want_lanes = schedule == OHW_SCHEDULE_LANES ? (int)std::min<int64_t>(e->lanes, n_dbatches) : 0;
+        if (schedule == OHW_SCHEDULE_PIPELINE) {
+          while (rc == OHW_OK && (int)e->states.size() < 2) {
+            ohw_state* st = nullptr;
+            rc = ohw_state_create(e->ctx, e->max_batch, &st);
+            if (rc == OHW_OK) e->states.push_back(st);
+          }
         }
         if (rc == OHW_OK && schedule == OHW_SCHEDULE_PIPELINE && !e->s_enc) {
           if (e->enc_cus >= total) e->enc_cus = std::max(1, total * 3 / 8);   // a smaller device: the same 3 : 5 split
           rc = ohw_stream_create(e->device, 0, e->enc_cus, &e->s_enc);
           if (rc == OHW_OK) rc = ohw_stream_create(e->device, e->enc_cus, total - e->enc_cus, &e->s_dec);
         }
-        if (rc == OHW_OK && schedule == OHW_SCHEDULE_LANES && (int)e->lane_streams.size() != want_states) {
-          for (void* ls : e->lane_streams) (void)ohw_stream_destroy(ls);     // another lane count: other CU ranges
-          e->lane_streams.clear();
-          const int per = std::max(1, total / want_states);
-          for (int i = 0; rc == OHW_OK && i < want_states; ++i) {
-            void* ls = nullptr;
-            rc = ohw_stream_create(e->device, i * per, per, &ls);
-            if (rc == OHW_OK) e->lane_streams.push_back(ls);
+        if (rc == OHW_OK && schedule == OHW_SCHEDULE_LANES) {
+          if (!e->lane_states.empty() && e->lane_capacity != (int)DBw) {      // another merge factor since the last call
+            for (ohw_state* st : e->lane_states) ohw_state_free(st);
+            e->lane_states.clear();
+          }
+          e->lane_capacity = (int)DBw;
+          while (rc == OHW_OK && (int)e->lane_states.size() < want_lanes) {
+            ohw_state* st = nullptr;
+            rc = ohw_state_create(e->ctx, (int)DBw, &st);
+            if (rc == OHW_OK) e->lane_states.push_back(st);
+          }
+          if (rc == OHW_OK && want_lanes >= 2 && (int)e->lane_streams.size() < want_lanes) {
+            for (void* ls : e->lane_streams) (void)ohw_stream_destroy(ls);     // another lane count: other CU ranges
+            e->lane_streams.clear();
+            const int per = std::max(1, total / want_lanes);
+            for (int i = 0; rc == OHW_OK && i < want_lanes; ++i) {
+              void* ls = nullptr;
+              rc = ohw_stream_create(e->device, i * per, per, &ls);
+              if (rc == OHW_OK) e->lane_streams.push_back(ls);
+            }
           }
         }
         if (rc != OHW_OK) {
           // no CU-masked queues (or no memory for more states) here: one batch after the other from now on
           for (size_t i = 1; i < e->states.size(); ++i) ohw_state_free(e->states[i]);
           e->states.clear();
+          for (ohw_state* st : e->lane_states) ohw_state_free(st);
+          e->lane_states.clear();
           for (void* ls : e->lane_streams) (void)ohw_stream_destroy(ls);
           e->lane_streams.clear();
           for (void** st : {&e->s_full, &e->s_enc, &e->s_dec}) if (*st) { (void)ohw_stream_destroy(*st); *st = nullptr; }
           e->schedule = schedule = OHW_SCHEDULE_SEQUENTIAL;
         }
       }
-      if (schedule == OHW_SCHEDULE_LANES && (int)e->lane_streams.size() < 2) schedule = OHW_SCHEDULE_SEQUENTIAL;
+      if (schedule == OHW_SCHEDULE_LANES && e->lane_states.empty()) schedule = OHW_SCHEDULE_SEQUENTIAL;
       if (schedule == OHW_SCHEDULE_PIPELINE && (e->states.size() < 2 || !e->s_enc)) schedule = OHW_SCHEDULE_SEQUENTIAL;
-      auto restore = [&] { for (ohw_state* st : e->states) (void)ohw_state_set_stream(st, nullptr); (void)ohw_state_set_stream(e->state, nullptr); };
+      auto restore = [&] {
+        for (ohw_state* st : e->states) (void)ohw_state_set_stream(st, nullptr);
+        for (ohw_state* st : e->lane_states) (void)ohw_state_set_stream(st, nullptr);
+        (void)ohw_state_set_stream(e->state, nullptr);
+      };
       if (schedule == OHW_SCHEDULE_SEQUENTIAL) {
         Scratch sc(e->max_batch, max_tok);
         std::vector<int32_t> ns((size_t)e->max_batch);
@@ -440,35 +466,51 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
         }
         restore();
       } else {
-        // LANES: groups of L batches.  Their front ends run one after the other on every CU (MFMA-bound: nothing to gain
-        // from sharing the chip), then their L decodes run side by side, each on its own CU-masked stream driven by its own
-        // host thread: a decode alternates an HBM-bound kernel (cross-attention) with a chain of latency-bound ones, and L
-        // of them together keep HBM busy (4 decodes of 32 large-v3 windows: 1.45-1.56x the rate of one after the other,
-        // tools/decode_overlap_probe.py).  Results are identical to the sequential schedule: the kernels' arithmetic
-        // does not depend on the CU budget.
-        const int L = (int)e->lane_streams.size();
+        // LANES: groups of L decode batches, each of up to `merge` front-end batches.  The front ends (max_batch windows each)
+        // run one after the other on every CU (MFMA-bound: nothing to gain from sharing the chip) and write their cross K/V
+        // into their lane's decode batch (ohw_encode_slice: the decoder streams its weights once per step whatever its
+        // batch); then the L decodes run side by side, each on its own CU-masked stream driven by its own host thread - a
+        // decode alternates an HBM-bound kernel (cross-attention) with a chain of latency-bound ones, and several together
+        // keep HBM busy (tools/decode_overlap_probe.py).  The kernels' arithmetic does not depend on the CU budget or on a
+        // window's batch neighbours, so the results equal the sequential schedule's.
+        const int L = std::max(1, (int)std::min(e->lane_states.size(), e->lane_streams.empty() ? (size_t)1 : e->lane_streams.size()));
+        const int merge = std::max(1, e->merge);
+        const int64_t DBw = (int64_t)e->max_batch * merge;                  // windows per decode batch
+        const int64_t n_db = (n_win + DBw - 1) / DBw;
         std::vector<std::unique_ptr<Scratch>> scs;
-        std::vector<std::vector<int32_t>> nss((size_t)L, std::vector<int32_t>((size_t)e->max_batch));
-        for (int i = 0; i < L; ++i) scs.emplace_back(new Scratch(e->max_batch, max_tok));
+        std::vector<std::vector<int32_t>> nss((size_t)L, std::vector<int32_t>((size_t)DBw));
+        for (int i = 0; i < L; ++i) scs.emplace_back(new Scratch((int)DBw, max_tok));
+        auto db_windows = [&](int64_t di) { return (int)std::min<int64_t>(DBw, n_win - di * DBw); };
         try {
-          for (int64_t g0 = 0; g0 < n_batches; g0 += L) {
-            const int grp = (int)std::min<int64_t>(L, n_batches - g0);
-            for (int j = 0; j < grp; ++j) front(g0 + j, e->states[(size_t)j], e->s_full, nss[(size_t)j]);
+          for (int64_t g0 = 0; g0 < n_db; g0 += L) {
+            const int grp = (int)std::min<int64_t>(L, n_db - g0);
+            for (int j = 0; j < grp; ++j) {
+              const int64_t w0 = (g0 + j) * DBw;
+              const int Wd = db_windows(g0 + j);
+              ohw_state* st = e->lane_states[(size_t)j];
+              check(ohw_state_set_stream(st, e->s_full));
+              for (int f = 0; f < Wd; f += e->max_batch) {
+                const int Bf = std::min(e->max_batch, Wd - f);
+                for (int b = 0; b < Bf; ++b) nss[(size_t)j][(size_t)(f + b)] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + f + b) * CHUNK_SAMPLES);
+                check(ohw_mel(st, samples + (w0 + f) * CHUNK_SAMPLES, CHUNK_SAMPLES, &nss[(size_t)j][(size_t)f], Bf, 0, OHW_MEL_ZERO_TAIL, nullptr));
+                check(ohw_encode_slice(st, Bf, f, Wd));
+              }
+            }
             if (grp == 1) {
-              decode_batch(*scs[0], e->states[0], g0, nss[0].data());
-              collect(*scs[0], batch_of(g0));
+              decode_windows(*scs[0], e->lane_states[0], g0 * DBw, db_windows(g0), nss[0].data());
+              collect(*scs[0], db_windows(g0));
               continue;
             }
             std::vector<std::string> errs((size_t)grp);
             std::vector<std::thread> th;
             for (int j = 0; j < grp; ++j) {
               check(ohw_stream_wait(e->lane_streams[(size_t)j], e->s_full));
-              check(ohw_state_set_stream(e->states[(size_t)j], e->lane_streams[(size_t)j]));
+              check(ohw_state_set_stream(e->lane_states[(size_t)j], e->lane_streams[(size_t)j]));
             }
             for (int j = 0; j < grp; ++j)
               th.emplace_back([&, j] {
                 try {
-                  decode_batch(*scs[(size_t)j], e->states[(size_t)j], g0 + j, nss[(size_t)j].data());
+                  decode_windows(*scs[(size_t)j], e->lane_states[(size_t)j], (g0 + j) * DBw, db_windows(g0 + j), nss[(size_t)j].data());
                 } catch (const std::exception& ex) {
                   errs[(size_t)j] = ex.what()[0] ? ex.what() : "unknown error";
                 }
@@ -480,7 +522,7 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
             for (int j = 0; j < grp; ++j) if (!errs[(size_t)j].empty()) throw Error(OHW_E_TRANSCRIBE, errs[(size_t)j]);
             for (int j = 0; j < grp; ++j) {
               check(ohw_stream_wait(e->s_full, e->lane_streams[(size_t)j]));
-              collect(*scs[(size_t)j], batch_of(g0 + j));
+              collect(*scs[(size_t)j], db_windows(g0 + j));
             }
           }
         } catch (...) {
@@ -695,6 +737,7 @@ void ohw_engine_free(ohw_engine* e) {
   if (!e) return;
   ohw_state_free(e->state);
   for (size_t i = 1; i < e->states.size(); ++i) ohw_state_free(e->states[i]);
+  for (ohw_state* st : e->lane_states) ohw_state_free(st);
   for (void* ls : e->lane_streams) (void)ohw_stream_destroy(ls);
   for (void* st : {e->s_full, e->s_enc, e->s_dec}) if (st) (void)ohw_stream_destroy(st);
   ohw_ctx_free(e->ctx);
@@ -772,10 +815,11 @@ int ohw_engine_last_quality(ohw_engine* e, const ohw_window_quality** q, int* n_
   return OHW_OK;
 }
 
-int ohw_engine_set_schedule(ohw_engine* e, int schedule, int lanes) {
-  if (!e || schedule < OHW_SCHEDULE_SEQUENTIAL || schedule > OHW_SCHEDULE_LANES || lanes < 0 || lanes > 16) return OHW_E_INVALID_ARG;
+int ohw_engine_set_schedule(ohw_engine* e, int schedule, int lanes, int merge) {
+  if (!e || schedule < OHW_SCHEDULE_SEQUENTIAL || schedule > OHW_SCHEDULE_LANES || lanes < 0 || lanes > 16 || merge < 0 || merge > 8) return OHW_E_INVALID_ARG;
   e->schedule = schedule;
   if (lanes > 0) e->lanes = lanes;
+  if (merge > 0) e->merge = std::min(merge, std::max(1, 256 / e->max_batch));
   return OHW_OK;
 }
 

@@ -20,9 +20,12 @@ struct ohw_engine {
   // and three streams, made on first use; enc_cus = 0 keeps the batches strictly one after the other
   std::vector<ohw_state*> states;        // states[0] == state; the others are made on the first long input
   std::vector<void*> lane_streams;       // LANES schedule: one CU-masked stream per decode lane
+  std::vector<ohw_state*> lane_states;   //   and one state of max_batch * merge windows per lane
+  int lane_capacity = 0;
   void* s_full = nullptr; void* s_enc = nullptr; void* s_dec = nullptr;
   int schedule = OHW_SCHEDULE_LANES;     // how audio longer than max_batch windows is overlapped (include/ohw.h)
-  int lanes = 4;                         // decodes side by side in the LANES schedule
+  int lanes = 2;                         // decodes side by side in the LANES schedule
+  int merge = 4;                         // front-end batches decoded together by one lane (ohw_encode_slice)
   int enc_cus = 96;
   int device = 0;
   ohw_decode_policy policy{0.2f, 2.4f, -1.0f, 0.6f};

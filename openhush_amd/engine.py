@@ -125,7 +125,7 @@ EXPORTS = [
     "ohw_greedy_ex", "ohw_state_set_logit_bias", "ohw_dbg_sample",
     "ohw_decode_active", "ohw_rng_new", "ohw_rng_free", "ohw_sample_host", "ohw_default_decode_policy", "ohw_engine_set_decode_policy",
     "ohw_engine_last_trace", "ohw_engine_set_schedule", "ohw_ctx_dtype",
-    "ohw_beam_search", "ohw_dsp_resample_sinc", "ohw_default_vad_config", "ohw_vad_state_new", "ohw_vad_state_free", "ohw_vad_state_update",
+    "ohw_beam_search", "ohw_encode_slice", "ohw_dsp_resample_sinc", "ohw_default_vad_config", "ohw_vad_state_new", "ohw_vad_state_free", "ohw_vad_state_update",
     "ohw_vad_state_is_speech", "ohw_vad_state_speech_start", "ohw_vad_state_reset", "ohw_vad_energy_engine", "ohw_vad_energy_engine_free",
     "ohw_vad_run",
     "ohw_pool_create", "ohw_pool_transcribe", "ohw_pool_last_text", "ohw_pool_last_tokens", "ohw_pool_last_quality",
@@ -231,6 +231,7 @@ def lib():
         L.ohw_state_max_batch.argtypes = [vp]
         L.ohw_mel.argtypes = [vp, vp, C.c_int64, ip, C.c_int, C.c_int, C.c_int, fp]
         L.ohw_encode.argtypes = [vp, C.c_int]
+        L.ohw_encode_slice.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.ohw_detect_language.argtypes = [vp, C.c_int, ip, fp]
         L.ohw_state_ctx.argtypes = [vp]
         L.ohw_state_ctx.restype = vp
@@ -258,7 +259,7 @@ def lib():
         L.ohw_engine_transcribe.argtypes = [vp, fp, C.c_int64, C.c_uint32, C.c_char_p, C.c_size_t, C.c_char_p,
                                             C.POINTER(C.c_uint64), C.POINTER(AudioInfo)]
         L.ohw_engine_set_window_mode.argtypes = [vp, C.c_int]
-        L.ohw_engine_set_schedule.argtypes = [vp, C.c_int, C.c_int]
+        L.ohw_engine_set_schedule.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.ohw_engine_last_quality.argtypes = [vp, C.POINTER(C.POINTER(WindowQuality)), C.POINTER(C.c_int)]
         L.ohw_engine_last_text.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
         L.ohw_engine_last_tokens.argtypes = [vp, C.POINTER(ip), C.POINTER(C.c_int)]
@@ -514,6 +515,10 @@ class State:
 
     def encode(self, batch: int):
         _check(lib().ohw_encode(self.h, batch))
+
+    def encode_slice(self, batch: int, first: int, total: int):
+        """encoder + cross K/V of the last mel's `batch` windows into windows [first, first + batch) of a decode batch of `total`"""
+        _check(lib().ohw_encode_slice(self.h, batch, first, total))
 
     def detect_language(self, batch: int):
         """(lang_ids [B], probs [B][n_langs]) for the windows of the last encode"""
@@ -889,9 +894,9 @@ class WhisperEngine:
         """OHW_WINDOW_FIXED (0, default) or OHW_WINDOW_SEEK (1, whisper.cpp's timestamp-driven loop)"""
         _check(lib().ohw_engine_set_window_mode(self.h, mode))
 
-    def set_schedule(self, schedule: int, lanes: int = 0):
+    def set_schedule(self, schedule: int, lanes: int = 0, merge: int = 0):
         """OHW_SCHEDULE_SEQUENTIAL / _PIPELINE / _LANES (default) for audio longer than max_batch windows"""
-        _check(lib().ohw_engine_set_schedule(self.h, schedule, lanes))
+        _check(lib().ohw_engine_set_schedule(self.h, schedule, lanes, merge))
 
     def last_tokens(self) -> List[int]:
         p = C.POINTER(C.c_int32)()

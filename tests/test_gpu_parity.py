@@ -297,13 +297,14 @@ def test_long_audio_overlapped_schedules_equal_sequential(E, models, monkeypatch
     _, path, _, _ = models
     pcm = np.concatenate([synth.synth_audio(30 + w) for w in range(5)] + [synth.synth_audio(36, 200000)])   # 6 windows, 3 batches
     out = {}
-    for name, sched, lanes, cus in (("seq", E.OHW_SCHEDULE_SEQUENTIAL, 0, "96"), ("lanes2", E.OHW_SCHEDULE_LANES, 2, "96"),
-                                    ("lanes3", E.OHW_SCHEDULE_LANES, 3, "96"), ("pipe96", E.OHW_SCHEDULE_PIPELINE, 0, "96"),
-                                    ("pipe200", E.OHW_SCHEDULE_PIPELINE, 0, "200")):
+    for name, sched, lanes, merge, cus in (("seq", E.OHW_SCHEDULE_SEQUENTIAL, 0, 0, "96"), ("lanes2", E.OHW_SCHEDULE_LANES, 2, 1, "96"),
+                                           ("lanes3", E.OHW_SCHEDULE_LANES, 3, 1, "96"), ("lanes2x2", E.OHW_SCHEDULE_LANES, 2, 2, "96"),
+                                           ("merge3", E.OHW_SCHEDULE_LANES, 2, 3, "96"), ("pipe96", E.OHW_SCHEDULE_PIPELINE, 0, 0, "96"),
+                                           ("pipe200", E.OHW_SCHEDULE_PIPELINE, 0, 0, "200")):
         monkeypatch.setenv("OHW_ENGINE_ENC_CUS", cus)          # read when the engine is created
         eng = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_BF16, 2)
         eng.set_decode_policy(temperature_inc=0.0)
-        eng.set_schedule(sched, lanes)
+        eng.set_schedule(sched, lanes, merge)
         r1 = eng.transcribe(E.AudioBuffer(pcm, 16000))
         t1 = eng.last_tokens()
         r2 = eng.transcribe(E.AudioBuffer(pcm[:480000 * 3 + 1000], 16000))     # the states and streams are reused (2 batches now)
@@ -574,3 +575,27 @@ def test_post_norm_gemms_match_the_layernorm_prologue(E, oracle, models, monkeyp
             print(f"dtype {dt} post-norm {mode}: worst logit error vs oracle {err:.4f}")
             assert err < TOL_LOGIT[dt], (dt, mode, err)
         assert float(np.abs(out[(dt, "1")] - out[(dt, "0")]).max()) < TOL_LOGIT[dt]
+
+
+def test_encode_slices_feed_one_decode_batch(E, models):
+    """ohw_encode_slice: two front-end passes (2 + 1 windows) into one decode batch of 3 == one front end of 3 windows."""
+    _, _, _, ctxs = models
+    ctx = ctxs[0]
+    pcm, ns = _pcm_batch()
+    p = ctx.default_params(); p.force_len = 20
+    st = E.State(ctx, 3)
+    st.mel(pcm, ns, E.OHW_MEL_ZERO_TAIL, want=False)
+    st.encode(3)
+    want, _ = st.greedy(3, p)
+    xk_want = st.fetch("xk1", 3)
+    st2 = E.State(ctx, 4)
+    st2.mel(pcm[:2], ns[:2], E.OHW_MEL_ZERO_TAIL, want=False)
+    st2.encode_slice(2, 0, 3)
+    st2.mel(pcm[2:], ns[2:], E.OHW_MEL_ZERO_TAIL, want=False)
+    st2.encode_slice(1, 2, 3)
+    got, _ = st2.greedy(3, p)
+    assert got == want and np.array_equal(st2.fetch("xk1", 3), xk_want)
+    with pytest.raises(E.WhisperError):
+        st2.encode_slice(1, 4, 5)             # past the state's max_batch
+    with pytest.raises(E.WhisperError):
+        st2.encode_slice(2, 0, 2)             # not the batch of the last mel
