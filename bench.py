@@ -52,11 +52,11 @@ def main():
     ap.add_argument("--decoders", type=int, default=1,
                     help="with --pipeline: decodes in flight beside the front end (each on its own CU-masked stream, driven by its own "
                          "host thread): the latency-bound GEMM chain of one decode hides under the K/V stream of the other")
-    ap.add_argument("--phases", type=int, default=2,
-                    help="G > 1 (default 2, the engine's LANES schedule): the front ends of G x --merge batches run one after the other on "
+    ap.add_argument("--phases", type=int, default=4,
+                    help="G > 1 (default 4, the engine's LANES schedule): the front ends of G x --merge batches run one after the other on "
                          "every CU, then G decodes side by side on G disjoint CU sets (one's latency-bound GEMM chain under the others' K/V "
                          "streams); 0 or 1: see --pipeline")
-    ap.add_argument("--merge", type=int, default=4,
+    ap.add_argument("--merge", type=int, default=2,
                     help="with --phases: batches decoded TOGETHER by one lane (ohw_encode_slice: their front ends feed one decode batch of "
                          "merge x batch rows - the decoder streams its weights once per step whatever its batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -334,6 +334,12 @@ def main():
                     shard.gather_tokens(shard.pack_tokens(toks_i, args.tokens), dist, world, rank, dev, force=True)
             return out[-1]
 
+    if pipe and G > 1:
+        # set-up, not a step: the decode graphs are captured per (state, decode-batch size) on first use and a capture holds
+        # the library's gate against every other lane, so each lane meets every group shape the K timed steps will use before
+        # the warm-up (K = 20 on 4 lanes x 2: groups of 8, 8 and 4)
+        for shape in sorted({min(G * MG, args.steps - g0) for g0 in range(0, args.steps, G * MG)}, reverse=True):
+            run_steps(shape)
     toks = run_steps(args.warmup)
 
     # ---- timed region: exactly K steps, no profiling hooks active (the decode loop replays its hipGraph)

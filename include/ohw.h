@@ -277,6 +277,14 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* p, int n_windows, in
  * src/engine/whisper.rs:243-263, so the default is no bias); tests use it to make end-of-text and timestamps win. */
 int ohw_state_set_logit_bias(ohw_state* st, const float* bias, int n);
 
+/* batch-invariant decoding (default off): the decoder picks some kernel variants from the number of rows in flight - up to
+ * 24 rows the keys of a cross-attention (row, head) are cut over several workgroups, and the prompt pass shares one K/V
+ * stream among a window's rows only when there are enough windows - and a different variant sums the softmax in a
+ * different order (last-bit differences in the logits).  With this on, the variant depends on n_new alone, so a window's
+ * logits and tokens are bit-identical whatever batch it is decoded in; tiny batches lose a little latency.
+ * ohw_engine_transcribe turns it on for audio longer than one batch, which makes its schedules agree token for token. */
+int ohw_state_set_batch_invariant(ohw_state* st, int on);
+
 /* per-stage device time of the last calls on this state, in milliseconds (reference logs the     */
 /* same split per job: src/queue/worker.rs:170-180)                                               */
 typedef struct { float mel_ms, encode_ms, decode_ms, total_ms; int32_t decode_steps; } ohw_timings;

@@ -937,7 +937,9 @@ __global__ __launch_bounds__(XA_THREADS) void cross_attn_rows_kernel(const T* __
 
 template <typename T>
 void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out, int M, int n_new, int n_head, int t_len, float* partials,
-                       unsigned* tickets, int max_split_rows, const int32_t* done, hipStream_t s, int kv_group) {
+                       unsigned* tickets, int max_split_rows, const int32_t* done, hipStream_t s, int kv_group, bool batch_invariant) {
+  // batch_invariant: the kernel variant (and with it the order of the softmax reduction) is picked from n_new alone, never
+  // from the number of rows, so a window's result does not depend on how many windows share its batch
   // beam search: kv_group consecutive rows are the beams of ONE window and read the same cross K/V: one workgroup per
   // (window, head) streams it once for all of them (done: per window)
   if (kv_group > 1) {
@@ -954,11 +956,11 @@ void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out,
   }
   // fewer (row, head) pairs than two per CU: cut the keys (at most 8 slices, each at least a few hundred keys)
   int ks = 1;
-  if (partials && tickets && M <= max_split_rows) {
+  if (partials && tickets && M <= max_split_rows && !batch_invariant) {
     while (ks < XA_MAX_SPLIT && (int64_t)M * n_head * ks < 512 && t_len / (ks * 2) >= 64) ks *= 2;
   }
   // several new tokens per window and enough windows to fill the chip: one workgroup per (window, head) streams K/V once
-  if (n_new >= 2 && n_new <= 4 && M % n_new == 0 && (int64_t)(M / n_new) * n_head >= 256) {
+  if (n_new >= 2 && n_new <= 4 && M % n_new == 0 && ((int64_t)(M / n_new) * n_head >= 256 || batch_invariant)) {
     const dim3 grid(n_head, M / n_new);
     if (n_new == 2) hipLaunchKernelGGL((cross_attn_rows_kernel<T, 2>), grid, dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_head, t_len, done);
     else if (n_new == 3) hipLaunchKernelGGL((cross_attn_rows_kernel<T, 3>), grid, dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_head, t_len, done);
@@ -1373,7 +1375,7 @@ void launch_beam_step(const SamplerParams& p, const BeamParams& bp, int n_window
   template void launch_dec_gemm<T>(const DecGemmParams&, int, hipStream_t); \
   template void launch_embed<T>(const void*, const float*, const int32_t*, const int32_t*, float*, void*, float*, int, int, int, hipStream_t); \
   template void launch_self_attn<T>(const void*, const void*, const void*, const int32_t*, void*, int, int, int, int, hipStream_t, const int32_t*); \
-  template void launch_cross_attn<T>(const void*, const void*, const void*, void*, int, int, int, int, float*, unsigned*, int, const int32_t*, hipStream_t, int);
+  template void launch_cross_attn<T>(const void*, const void*, const void*, void*, int, int, int, int, float*, unsigned*, int, const int32_t*, hipStream_t, int, bool);
 INST(bf16_t)
 INST(f16_t)
 #undef INST

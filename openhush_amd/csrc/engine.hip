@@ -115,7 +115,8 @@ struct ohw_state {
   double prof_work = 0.0;
   // hipGraph of one greedy iteration {feed sampled token, single-token decoder step, sampler}
   // captured greedy iterations, one per (batch, sampler parameters, CU budget of the stream) seen; a handful at most
-  struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int batch = 0; int cus = 0; SamplerParams spar{}; };
+  struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int batch = 0; int cus = 0; bool invariant = false; SamplerParams spar{}; };
+  bool batch_invariant = false;      // cross-attention variant picked from n_new alone (state_set_batch_invariant)
   std::vector<StepGraph> step_graphs;
   bool graphs_enabled = true;
   // timing
@@ -350,11 +351,11 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
     {
       // algorithmic bytes: K and V of every (query row, head); the prompt pass streams them once per (window, head)
       // for all its rows (cross_attn_rows_kernel: same condition as launch_cross_attn)
-      const bool rows_path = n_new >= 2 && n_new <= 4 && (int64_t)B * H >= 256;
+      const bool rows_path = n_new >= 2 && n_new <= 4 && ((int64_t)B * H >= 256 || st->batch_invariant);
       ProfScope psx(st, OHW_PROF_DEC_XATTN, 2.0 * 2.0 * (double)(kv_group > 1 ? B / kv_group : rows_path ? B : M) * H * Tn * 64.0);
       launch_cross_attn<T>(st->dq.p, (const T*)st->xkv.p + (int64_t)(2 * l) * xkv_slab, (const T*)st->xkv.p + (int64_t)(2 * l + 1) * xkv_slab,
                            st->da.p, M, n_new, H, Tn, st->xa_part.as<float>(), st->xa_ticket.as<unsigned>(), st->xa_rows,
-                           kv_group > 1 ? win_done : (st->skip_done ? st->done.as<int32_t>() : nullptr), s, kv_group);
+                           kv_group > 1 ? win_done : (st->skip_done ? st->done.as<int32_t>() : nullptr), s, kv_group, st->batch_invariant);
     }
     gemm(st->da.p, nullptr, w.wxo, w.bxo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
     gemm(st->dx.p, &w.ln2, w.w1, w.b1, st->df.p, 4 * d, d, DEPI_BIAS_GELU_T, 4 * d, &w.s1);
@@ -714,7 +715,7 @@ int ohw_greedy_ex(ohw_state* st, const ohw_sample_params* sp, int batch, int max
       hipGraphExec_t step_exec = nullptr;
       if (use_graph) {
         for (auto& g : st->step_graphs)
-          if (g.batch == batch && g.cus == st->stream_cus && std::memcmp(&g.spar, &spar, sizeof spar) == 0) step_exec = g.exec;
+          if (g.batch == batch && g.cus == st->stream_cus && g.invariant == st->batch_invariant && std::memcmp(&g.spar, &spar, sizeof spar) == 0) step_exec = g.exec;
       }
       if (use_graph && !step_exec) {
         if (st->step_graphs.size() >= 8) {     // bounded: drop the oldest capture
@@ -749,7 +750,7 @@ int ohw_greedy_ex(ohw_state* st, const ohw_sample_params* sp, int batch, int max
         HIP_CHECK(hipStreamEndCapture(cap, &ng.graph));
         hipError_t ie = hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0);
         if (ie != hipSuccess) { (void)hipGraphDestroy(ng.graph); HIP_CHECK(ie); }
-        ng.batch = batch; ng.cus = st->stream_cus; ng.spar = spar;
+        ng.batch = batch; ng.cus = st->stream_cus; ng.invariant = st->batch_invariant; ng.spar = spar;
         st->step_graphs.push_back(ng);
         step_exec = ng.exec;
       }
@@ -961,6 +962,12 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* sp, int n_windows, i
     }
     st->last.decode_steps = steps;
   });
+}
+
+int ohw_state_set_batch_invariant(ohw_state* st, int on) {
+  if (!st) return OHW_E_INVALID_ARG;
+  st->batch_invariant = on != 0;
+  return OHW_OK;
 }
 
 int ohw_state_set_logit_bias(ohw_state* st, const float* bias, int n) {

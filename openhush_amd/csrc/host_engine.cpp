@@ -303,7 +303,15 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
       void reset(size_t nr) { for (ohw_rng* r : v) ohw_rng_free(r); v.clear(); for (size_t i = 0; i < nr; ++i) v.push_back(ohw_rng_new(0)); }
     } rngs;
 
-    auto flush_trace = [&](Scratch& sc) { e->last_trace.insert(e->last_trace.end(), sc.trace.begin(), sc.trace.end()); sc.trace.clear(); };
+    // a batch records its passes in the order it ran them (every window's T = 0 pass, then the ladder's rungs); the trace lists
+    // them window by window, each window's passes in order, so it reads the same however the windows were batched
+    auto flush_trace = [&](Scratch& sc) {
+      std::vector<std::pair<int32_t, size_t>> recs;            // (window, offset of the record)
+      for (size_t i = 0; i + 3 <= sc.trace.size(); i += 3 + (size_t)sc.trace[i + 2]) recs.emplace_back(sc.trace[i], i);
+      std::stable_sort(recs.begin(), recs.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+      for (const auto& r : recs) e->last_trace.insert(e->last_trace.end(), sc.trace.begin() + (long)r.second, sc.trace.begin() + (long)(r.second + 3 + (size_t)sc.trace[r.second + 2]));
+      sc.trace.clear();
+    };
     if (e->window_mode == OHW_WINDOW_SEEK) {
       // whisper.cpp's seek loop as recalled: sequential windows, advanced by the last timestamp; one
       // generator for the whole call
@@ -372,9 +380,7 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
         if (e->states.empty()) e->states.assign(1, e->state);
         // LANES: decode batches of up to merge front-end batches (ohw_encode_slice); lane states hold max_batch * merge windows
         const int merge = std::max(1, e->merge);
-        const int64_t DBw = (int64_t)e->max_batch * merge;
-        const int64_t n_dbatches = (n_win + DBw - 1) / DBw;
-        const int want_lanes = schedule == OHW_SCHEDULE_LANES ? (int)std::min<int64_t>(e->lanes, n_dbatches) : 0;
+        const int want_lanes = schedule == OHW_SCHEDULE_LANES ? (int)std::min<int64_t>(e->lanes, n_batches) : 0;
         if (schedule == OHW_SCHEDULE_PIPELINE) {
           while (rc == OHW_OK && (int)e->states.size() < 2) {
             ohw_state* st = nullptr;
@@ -388,17 +394,20 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
           if (rc == OHW_OK) rc = ohw_stream_create(e->device, e->enc_cus, total - e->enc_cus, &e->s_dec);
         }
         if (rc == OHW_OK && schedule == OHW_SCHEDULE_LANES) {
-          if (!e->lane_states.empty() && e->lane_capacity != (int)DBw) {      // another merge factor since the last call
+          // a lane's state holds what this input can put into one decode batch (cross K/V is 245.76 MB per window at large-v3)
+          const int64_t per_lane = std::min<int64_t>(merge, (n_batches + want_lanes - 1) / std::max(1, want_lanes));
+          const int need = (int)(e->max_batch * per_lane);
+          if (!e->lane_states.empty() && e->lane_capacity < need) {            // a longer input (or another merge factor) than before
             for (ohw_state* st : e->lane_states) ohw_state_free(st);
             e->lane_states.clear();
           }
-          e->lane_capacity = (int)DBw;
+          if (e->lane_states.empty()) e->lane_capacity = need;
           while (rc == OHW_OK && (int)e->lane_states.size() < want_lanes) {
             ohw_state* st = nullptr;
-            rc = ohw_state_create(e->ctx, (int)DBw, &st);
+            rc = ohw_state_create(e->ctx, e->lane_capacity, &st);
             if (rc == OHW_OK) e->lane_states.push_back(st);
           }
-          if (rc == OHW_OK && want_lanes >= 2 && (int)e->lane_streams.size() < want_lanes) {
+          if (rc == OHW_OK && want_lanes >= 2 && (int)e->lane_streams.size() != want_lanes) {
             for (void* ls : e->lane_streams) (void)ohw_stream_destroy(ls);     // another lane count: other CU ranges
             e->lane_streams.clear();
             const int per = std::max(1, total / want_lanes);
@@ -423,6 +432,18 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
       }
       if (schedule == OHW_SCHEDULE_LANES && e->lane_states.empty()) schedule = OHW_SCHEDULE_SEQUENTIAL;
       if (schedule == OHW_SCHEDULE_PIPELINE && (e->states.size() < 2 || !e->s_enc)) schedule = OHW_SCHEDULE_SEQUENTIAL;
+      // audio longer than one batch: kernel variants no longer picked from a batch's row count, so a window decodes to the
+      // same bits whichever batch (a short last one, a merged one) and schedule it lands in (include/ohw.h)
+      struct Invariant {
+        ohw_engine* e; bool on;
+        void set(bool v) {
+          (void)ohw_state_set_batch_invariant(e->state, v);
+          for (ohw_state* st : e->states) (void)ohw_state_set_batch_invariant(st, v);
+          for (ohw_state* st : e->lane_states) (void)ohw_state_set_batch_invariant(st, v);
+        }
+        Invariant(ohw_engine* e_, bool on_) : e(e_), on(on_) { if (on) set(true); }
+        ~Invariant() { if (on) set(false); }
+      } invariant(e, n_batches > 1);
       auto restore = [&] {
         for (ohw_state* st : e->states) (void)ohw_state_set_stream(st, nullptr);
         for (ohw_state* st : e->lane_states) (void)ohw_state_set_stream(st, nullptr);
@@ -474,19 +495,30 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
         // keep HBM busy (tools/decode_overlap_probe.py).  The kernels' arithmetic does not depend on the CU budget or on a
         // window's batch neighbours, so the results equal the sequential schedule's.
         const int L = std::max(1, (int)std::min(e->lane_states.size(), e->lane_streams.empty() ? (size_t)1 : e->lane_streams.size()));
-        const int merge = std::max(1, e->merge);
-        const int64_t DBw = (int64_t)e->max_batch * merge;                  // windows per decode batch
-        const int64_t n_db = (n_win + DBw - 1) / DBw;
+        const int merge = std::max(1, std::min(e->merge, e->lane_capacity / std::max(1, e->max_batch)));
+        const int64_t DBw = (int64_t)e->max_batch * merge;                  // capacity of a lane's decode batch, windows
         std::vector<std::unique_ptr<Scratch>> scs;
         std::vector<std::vector<int32_t>> nss((size_t)L, std::vector<int32_t>((size_t)DBw));
         for (int i = 0; i < L; ++i) scs.emplace_back(new Scratch((int)DBw, max_tok));
-        auto db_windows = [&](int64_t di) { return (int)std::min<int64_t>(DBw, n_win - di * DBw); };
         try {
-          for (int64_t g0 = 0; g0 < n_db; g0 += L) {
-            const int grp = (int)std::min<int64_t>(L, n_db - g0);
+          // a group = up to L * merge front-end batches, dealt to the lanes as evenly as they go (4 batches on 4 lanes are 4
+          // decode batches of one front end each, not one lane with all four)
+          for (int64_t b0 = 0; b0 < n_batches;) {
+            const int gb = (int)std::min<int64_t>((int64_t)L * merge, n_batches - b0);
+            const int grp = std::min(L, gb);
+            std::vector<int64_t> lane_w0((size_t)grp);
+            std::vector<int> lane_w((size_t)grp);
+            int64_t bnext = b0;
             for (int j = 0; j < grp; ++j) {
-              const int64_t w0 = (g0 + j) * DBw;
-              const int Wd = db_windows(g0 + j);
+              const int mj = gb / grp + (j < gb % grp ? 1 : 0);
+              lane_w0[(size_t)j] = bnext * e->max_batch;
+              lane_w[(size_t)j] = (int)(std::min<int64_t>(n_win, (bnext + mj) * e->max_batch) - lane_w0[(size_t)j]);
+              bnext += mj;
+            }
+            b0 = bnext;
+            for (int j = 0; j < grp; ++j) {
+              const int64_t w0 = lane_w0[(size_t)j];
+              const int Wd = lane_w[(size_t)j];
               ohw_state* st = e->lane_states[(size_t)j];
               check(ohw_state_set_stream(st, e->s_full));
               for (int f = 0; f < Wd; f += e->max_batch) {
@@ -497,8 +529,8 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
               }
             }
             if (grp == 1) {
-              decode_windows(*scs[0], e->lane_states[0], g0 * DBw, db_windows(g0), nss[0].data());
-              collect(*scs[0], db_windows(g0));
+              decode_windows(*scs[0], e->lane_states[0], lane_w0[0], lane_w[0], nss[0].data());
+              collect(*scs[0], lane_w[0]);
               continue;
             }
             std::vector<std::string> errs((size_t)grp);
@@ -510,7 +542,7 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
             for (int j = 0; j < grp; ++j)
               th.emplace_back([&, j] {
                 try {
-                  decode_windows(*scs[(size_t)j], e->lane_states[(size_t)j], (g0 + j) * DBw, db_windows(g0 + j), nss[(size_t)j].data());
+                  decode_windows(*scs[(size_t)j], e->lane_states[(size_t)j], lane_w0[(size_t)j], lane_w[(size_t)j], nss[(size_t)j].data());
                 } catch (const std::exception& ex) {
                   errs[(size_t)j] = ex.what()[0] ? ex.what() : "unknown error";
                 }
@@ -522,7 +554,7 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
             for (int j = 0; j < grp; ++j) if (!errs[(size_t)j].empty()) throw Error(OHW_E_TRANSCRIBE, errs[(size_t)j]);
             for (int j = 0; j < grp; ++j) {
               check(ohw_stream_wait(e->s_full, e->lane_streams[(size_t)j]));
-              collect(*scs[(size_t)j], db_windows(g0 + j));
+              collect(*scs[(size_t)j], lane_w[(size_t)j]);
             }
           }
         } catch (...) {

@@ -24,8 +24,8 @@ struct ohw_engine {
   int lane_capacity = 0;
   void* s_full = nullptr; void* s_enc = nullptr; void* s_dec = nullptr;
   int schedule = OHW_SCHEDULE_LANES;     // how audio longer than max_batch windows is overlapped (include/ohw.h)
-  int lanes = 2;                         // decodes side by side in the LANES schedule
-  int merge = 4;                         // front-end batches decoded together by one lane (ohw_encode_slice)
+  int lanes = 4;                         // decodes side by side in the LANES schedule
+  int merge = 2;                         // front-end batches decoded together by one lane (ohw_encode_slice)
   int enc_cus = 96;
   int device = 0;
   ohw_decode_policy policy{0.2f, 2.4f, -1.0f, 0.6f};

@@ -95,7 +95,8 @@ constexpr int XA_MAX_SPLIT = 8;
 template <typename T> void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out, int M, int n_new,
                                              int n_head, int t_len, float* partials, unsigned* tickets, int max_split_rows,
                                              const int32_t* done /* [B] or null: windows whose rows are skipped */, hipStream_t s,
-                                             int kv_group = 1 /* beam search: consecutive rows that share one window's K/V */);
+                                             int kv_group = 1 /* beam search: consecutive rows that share one window's K/V */,
+                                             bool batch_invariant = false /* pick the variant from n_new alone, never from M */);
 
 // device-side logits filter + arg-max (restates oracle ref_process_logits)
 struct SamplerParams {

@@ -122,7 +122,7 @@ EXPORTS = [
     "ohw_ctx_create_shell", "ohw_ctx_blob_size", "ohw_ctx_blob_export", "ohw_ctx_blob_import",
     "ohw_default_preprocess_config", "ohw_preprocess_audio", "ohw_dsp_rms_db", "ohw_dsp_apply_gain", "ohw_dsp_normalize_rms",
     "ohw_dsp_compress", "ohw_dsp_limit", "ohw_dsp_resample_linear",
-    "ohw_greedy_ex", "ohw_state_set_logit_bias", "ohw_dbg_sample",
+    "ohw_greedy_ex", "ohw_state_set_logit_bias", "ohw_state_set_batch_invariant", "ohw_dbg_sample",
     "ohw_decode_active", "ohw_rng_new", "ohw_rng_free", "ohw_sample_host", "ohw_default_decode_policy", "ohw_engine_set_decode_policy",
     "ohw_engine_last_trace", "ohw_engine_set_schedule", "ohw_ctx_dtype",
     "ohw_beam_search", "ohw_encode_slice", "ohw_dsp_resample_sinc", "ohw_default_vad_config", "ohw_vad_state_new", "ohw_vad_state_free", "ohw_vad_state_update",
@@ -242,6 +242,7 @@ def lib():
         L.ohw_greedy.argtypes = [vp, C.POINTER(SampleParams), C.c_int, ip, ip, C.c_int, fp]
         L.ohw_greedy_ex.argtypes = [vp, C.POINTER(SampleParams), C.c_int, C.c_int, C.POINTER(GreedyResult)]
         L.ohw_state_set_logit_bias.argtypes = [vp, fp, C.c_int]
+        L.ohw_state_set_batch_invariant.argtypes = [vp, C.c_int]
         L.ohw_beam_search.argtypes = [vp, C.POINTER(SampleParams), C.c_int, C.c_int, C.c_int, C.POINTER(BeamResult)]
         L.ohw_dbg_sample.argtypes = [vp, C.POINTER(SampleParams), fp, ip, C.c_int, ip, C.c_int, ip, fp, fp]
         L.ohw_decode_active.argtypes = [vp, ip, C.c_int, ip, C.c_int, ip, fp]
@@ -592,6 +593,10 @@ class State:
             b = np.ascontiguousarray(bias, dtype=np.float32)
             _check(lib().ohw_state_set_logit_bias(self.h, _fp(b), b.size))
 
+    def set_batch_invariant(self, on: bool = True):
+        """ohw_state_set_batch_invariant: kernel variants picked from n_new alone - a window's result no longer depends on its batch"""
+        _check(lib().ohw_state_set_batch_invariant(self.h, int(bool(on))))
+
     def dbg_sample(self, p: SampleParams, logits: np.ndarray, histories: Sequence[Sequence[int]]):
         """the DEVICE sampler on caller-supplied rows -> (tokens [B], logprobs [B], no_speech_prob [B])"""
         lg = np.ascontiguousarray(np.atleast_2d(logits), dtype=np.float32)
@@ -800,6 +805,31 @@ def vad_segments(samples: np.ndarray, config: VadConfig, poll_samples: int = 800
     if n < 0:
         _check(n)
     return [(int(segs[i].start), int(segs[i].end), float(segs[i].avg_probability)) for i in range(min(n, cap))]
+
+
+class EnergyVad:
+    """the built-in energy detector as a VadEngine (process(samples) -> probability): ohw_vad_energy_engine.  Not Silero."""
+    def __init__(self, threshold_db: float = -40.0):
+        self.eng = VadEngineC()
+        _check(lib().ohw_vad_energy_engine(threshold_db, C.byref(self.eng)))
+
+    def __call__(self, samples: np.ndarray) -> float:
+        x = np.ascontiguousarray(samples, dtype=np.float32)
+        out = C.c_float(0.0)
+        if self.eng.process(self.eng.user, _fp(x) if x.size else C.cast(None, C.POINTER(C.c_float)), x.size, C.byref(out)) != 0:
+            raise WhisperError("vad process failed")
+        return float(out.value)
+
+    def close(self):
+        if self.eng is not None:
+            lib().ohw_vad_energy_engine_free(C.byref(self.eng))
+            self.eng = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass
 
 
 @dataclasses.dataclass

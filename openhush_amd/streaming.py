@@ -1,0 +1,114 @@
+"""Streaming glue around the path (BASELINE.json config #5): the daemon's chunk scheduler in front of the
+engine and the TranscriptionTracker behind it, host side.
+
+    ChunkScheduler     <- the chunk-timer arm of the daemon loop (reference src/daemon.rs:1912-2013) + AudioRecorder::
+                          extract_chunk (src/input/audio.rs:741-776): on every tick the audio since the last tick becomes a job
+                          (dropped below 0.1 s, padded to 1.1 s), registered with the tracker under its back-pressure settings
+    StreamingSession   ties it to the MI355X path: an optional VAD gate (reference VadEngine hook: chunks without speech are
+                          not decoded), one 30 s window per chunk through mel -> encoder -> beam search (beam = 5, the
+                          hipGraph-captured decoder step) or the greedy loop, detokenise, tracker.add_result ->
+                          take_ready (overlap de-duplication and ordering are the tracker's)
+Nothing here computes: the arithmetic is in libohw.so.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from . import engine as E
+from .tracker import BackpressureStrategy, ChunkResult, TranscriptionTracker
+
+SAMPLE_RATE = 16000
+MIN_DURATION_SECS = 0.1            # reference src/input/audio.rs:29
+WHISPER_MIN_DURATION_SECS = 1.1    # reference src/input/audio.rs:34
+
+
+@dataclasses.dataclass
+class ChunkJob:
+    """reference src/queue/mod.rs TranscriptionJob"""
+    samples: np.ndarray
+    sequence_id: int
+    chunk_id: int
+    is_final: bool = False
+
+
+def extract_chunk(recording: np.ndarray, from_pos: int, to_pos: int) -> Optional[np.ndarray]:
+    """AudioRecorder::extract_chunk for a 16 kHz recorder: None below 0.1 s, zero-padded to 1.1 s (17 600 samples)"""
+    s = np.asarray(recording[from_pos:to_pos], dtype=np.float32)
+    if s.size == 0 or s.size / SAMPLE_RATE < MIN_DURATION_SECS:
+        return None
+    need = int(SAMPLE_RATE * WHISPER_MIN_DURATION_SECS)
+    if s.size / SAMPLE_RATE < WHISPER_MIN_DURATION_SECS:
+        s = np.concatenate([s, np.zeros(need - s.size, np.float32)])
+    return s
+
+
+class ChunkScheduler:
+    """One recording (sequence): tick(current_pos) returns the job for the audio since the last tick, or None (too short, or
+    refused by the tracker's back-pressure - the position still advances, as in the reference)."""
+
+    def __init__(self, tracker: TranscriptionTracker, sequence_id: int, max_pending: int = 10, high_water_mark: int = 8,
+                 strategy: BackpressureStrategy = BackpressureStrategy.WARN):
+        self.tracker, self.sequence_id = tracker, sequence_id
+        self.max_pending, self.high_water_mark, self.strategy = max_pending, high_water_mark, strategy
+        self.last_chunk_pos = 0
+        self.next_chunk_id = 0
+        self.rejected = 0
+
+    def tick(self, recording: np.ndarray, current_pos: int, is_final: bool = False) -> Optional[ChunkJob]:
+        buf = extract_chunk(recording, self.last_chunk_pos, current_pos)
+        if buf is None:
+            return None                                   # "Chunk too short, skipping": the position is kept
+        accepted = self.tracker.add_pending_with_config(self.sequence_id, self.next_chunk_id, self.max_pending, self.high_water_mark,
+                                                        self.strategy)
+        job = ChunkJob(buf, self.sequence_id, self.next_chunk_id, is_final) if accepted else None
+        if not accepted:
+            self.rejected += 1
+        self.last_chunk_pos = current_pos
+        self.next_chunk_id += 1
+        return job
+
+
+class StreamingSession:
+    """Chunks of one recording through the MI355X path.  beam_size 0 = greedy; vad: callable samples -> probability (the
+    VadEngine hook) with `vad_threshold`, or None."""
+
+    def __init__(self, ctx: E.Context, beam_size: int = 5, vad: Optional[Callable[[np.ndarray], float]] = None, vad_threshold: float = 0.5,
+                 sequence_id: int = 1, tracker: Optional[TranscriptionTracker] = None, params: Optional[E.SampleParams] = None):
+        self.ctx = ctx
+        self.beam_size = beam_size
+        self.state = E.State(ctx, max(1, beam_size))          # one window per chunk: beam_size decoder rows
+        self.vad, self.vad_threshold = vad, vad_threshold
+        self.tracker = tracker or TranscriptionTracker()
+        self.scheduler = ChunkScheduler(self.tracker, sequence_id)
+        self.params = params or ctx.default_params()
+        self.skipped_silent = 0
+
+    def _text(self, tokens: List[int]) -> str:
+        return b"".join(self.ctx.token_text(t) for t in tokens if t < self.ctx.tok.eot).decode("utf-8", "replace").strip()
+
+    def transcribe_job(self, job: ChunkJob) -> ChunkResult:
+        s = job.samples[:E.CHUNK_SAMPLES]
+        if self.vad is not None and float(self.vad(s)) < self.vad_threshold:
+            self.skipped_silent += 1
+            text = ""
+        else:
+            self.state.mel(s[None, :], [len(s)], E.OHW_MEL_ZERO_TAIL, want=False)
+            self.state.encode(1)
+            if self.beam_size >= 2:
+                toks = self.state.beam_search(1, self.beam_size, self.params)[0]["tokens"]
+            else:
+                toks = self.state.greedy(1, self.params)[0][0]
+            text = self._text(toks)
+        return ChunkResult(text, job.sequence_id, job.chunk_id, job.is_final, len(job.samples) / SAMPLE_RATE)
+
+    def tick(self, recording: np.ndarray, current_pos: int, is_final: bool = False) -> List[ChunkResult]:
+        """the daemon's chunk-timer arm and the worker in one call: schedule, transcribe, hand to the tracker, return what the
+        tracker releases"""
+        job = self.scheduler.tick(recording, current_pos, is_final)
+        if job is None:
+            return []
+        self.tracker.add_result(self.transcribe_job(job))
+        return self.tracker.take_ready()

@@ -171,7 +171,7 @@ def test_config4_one_hour_120_windows_on_one_gpu(E, large_v3_file, monkeypatch):
     for cus, sched in (("lanes", E.OHW_SCHEDULE_LANES), ("96", E.OHW_SCHEDULE_PIPELINE), ("0", E.OHW_SCHEDULE_SEQUENTIAL)):
         eng = E.WhisperEngine.new(large_v3_file, "auto", False, True, 0, E.OHW_DTYPE_BF16, 32)
         eng.set_decode_policy(temperature_inc=0.0)           # T = 0 only: the fallback ladder is a per-window host path
-        eng.set_schedule(sched)                              # LANES: the defaults, 2 lanes x 4 merged batches = 128-row decodes
+        eng.set_schedule(sched)                              # LANES: the defaults (4 lanes; 4 batches = one per lane)
         eng.transcribe(E.AudioBuffer(pcm, 16000))                    # warm-up: states, streams, graph captures
         t0 = time.perf_counter()
         res = eng.transcribe(E.AudioBuffer(pcm, 16000))
@@ -200,6 +200,13 @@ def test_config4_one_hour_120_windows_on_one_gpu(E, large_v3_file, monkeypatch):
             st1.close()
         eng.close()
     assert out["96"] == out["0"] and out["lanes"] == out["0"]
+    # merged decode batches: 2 lanes x 2 front-end batches = decodes of 64 and 56 rows (the sequential schedule's last batch has 24)
+    eng = E.WhisperEngine.new(large_v3_file, "auto", False, True, 0, E.OHW_DTYPE_BF16, 32)
+    eng.set_decode_policy(temperature_inc=0.0)
+    eng.set_schedule(E.OHW_SCHEDULE_LANES, 2, 2)
+    res = eng.transcribe(E.AudioBuffer(pcm, 16000))
+    assert (res.text, eng.last_tokens(), [x[0] for x in eng.last_quality()]) == out["0"]
+    eng.close()
     assert len(out["0"][0]) > 0
 
 

@@ -313,15 +313,55 @@ def test_long_audio_overlapped_schedules_equal_sequential(E, models, monkeypatch
     for name in out:
         assert out[name] == out["seq"], name
     assert len(out["seq"][4]) == 4
-    # the default is LANES with 4 lanes; with the temperature ladder on (micro weights fail every pass) the lanes run the
+    # the default is LANES (4 lanes x up to 2 merged batches); with the temperature ladder on (micro weights fail every pass) the lanes run the
     # host-sampled fallback side by side and still agree with the sequential schedule
     e1 = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_F16, 1)
     e2 = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_F16, 1)
+    e3 = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_F16, 1)
     e2.set_schedule(E.OHW_SCHEDULE_SEQUENTIAL)
+    e3.set_schedule(E.OHW_SCHEDULE_LANES, 2, 2)        # lanes of 2 and 1 windows: merged decode batches, other row counts
     short = pcm[:480000 * 2 + 100000]
-    a, b2 = e1.transcribe(E.AudioBuffer(short, 16000)), e2.transcribe(E.AudioBuffer(short, 16000))
+    a, b2, c3 = (e.transcribe(E.AudioBuffer(short, 16000)) for e in (e1, e2, e3))
     assert a.text == b2.text and e1.last_trace() == e2.last_trace() and len(e1.last_trace()) == 18
-    e1.close(); e2.close()
+    assert c3.text == b2.text and e3.last_trace() == e2.last_trace()      # batch-invariant kernels (ohw_state_set_batch_invariant)
+    e1.close(); e2.close(); e3.close()
+
+
+def test_batch_invariant_decode_is_independent_of_the_batch(E, models):
+    """ohw_state_set_batch_invariant: the same window alone, in a batch of 3 and (with 30 more) in a batch of 33 rows gives
+    bit-identical logits (prompt pass and single-token steps) and the same greedy tokens and log-probabilities; without the
+    switch the small batches cut cross-attention's keys over several workgroups (another summation order)."""
+    _, _, _, ctxs = models
+    ctx = ctxs[0]
+    pcm, ns = _pcm_batch()
+    big = np.concatenate([pcm] + [np.stack([synth.synth_audio(200 + i) for i in range(30)])])
+    nsb = list(ns) + [synth.CHUNK_SAMPLES] * 30
+    tok = ctx.tok
+    prompt = np.asarray([tok.sot, tok.sot + 1, tok.transcribe, tok.no_timestamps], np.int32)
+    p = ctx.default_params(); p.force_len = 24
+    res = {}
+    for B in (1, 3, 33):
+        st = E.State(ctx, B)
+        st.set_batch_invariant(True)
+        st.mel(big[:B], nsb[:B], E.OHW_MEL_ZERO_TAIL, want=False)
+        st.encode(B)
+        l0 = st.decode(np.tile(prompt, (B, 1)), [0] * B)
+        steps = []
+        cur = l0
+        for i in range(3):
+            cur = st.decode(cur.argmax(axis=1).astype(np.int32)[:, None], [4 + i] * B)
+            steps.append(cur)
+        g = st.greedy_ex(B, p)
+        res[B] = (l0, steps, g)
+        st.close()
+    for B in (1, 3):
+        l0, steps, g = res[B]
+        L0, Steps, G = res[33]
+        assert np.array_equal(l0, L0[:B]), B
+        for a, b in zip(steps, Steps):
+            assert np.array_equal(a, b[:B]), B
+        for a, b in zip(g, G[:B]):
+            assert a["tokens"] == b["tokens"] and np.array_equal(a["logprobs"], b["logprobs"]), B
 
 
 def test_cu_masked_streams_give_the_same_tokens(E, models):
