@@ -185,6 +185,18 @@ int ohw_stream_sync(void* stream);
 /* mel_out (optional, host or NULL): [batch][n_mels][3000] f32 copy of the normalised log-mel.     */
 int ohw_mel(ohw_state* st, const float* pcm, int64_t pcm_stride, const int32_t* n_samples, int batch,
             int pcm_on_device, int mel_mode, float* mel_out);
+
+/* The spectrogram of a WHOLE recording, windows cut from it afterwards - what whisper.cpp does inside state.full() for
+ * audio of any length (whisper_pcm_to_mel on all samples, then the encoder reads 3000 frames at the seek offset; reference
+ * src/engine/whisper.rs:266-268 hands the whole buffer over).  Against ohw_mel on the samples from the seek offset on, a
+ * window gets (a) the clamp `max - 8` from the maximum over ALL frames of the recording, (b) real neighbouring samples at
+ * its edges (the 200-sample reflection only at the recording's start, zeros only after its end).
+ *   ohw_recording_set: copies the recording (host, or device when pcm_on_device != 0; 1 .. 2 h of 16 kHz samples) into
+ *     the state and finds that maximum in one pass (log_max_out, optional: log10 of the largest mel power);
+ *   ohw_mel_seek: windows [seek_frames[b], +3000) (10 ms frames) of that spectrogram, for ohw_encode(batch) as after
+ *     ohw_mel; mel_out as there.  The engine's OHW_WINDOW_SEEK mode runs on these two. */
+int ohw_recording_set(ohw_state* st, const float* pcm, int64_t n, int pcm_on_device, float* log_max_out);
+int ohw_mel_seek(ohw_state* st, const int32_t* seek_frames, int batch, float* mel_out);
 /* encoder + cross-attention K/V of every decoder layer, for the windows of the last ohw_mel      */
 int ohw_encode(ohw_state* st, int batch);
 /* the same into windows [first, first + batch) of a decode batch of `total` windows (total <= max_batch): several front-end

@@ -79,6 +79,8 @@ struct ohw_state {
   hipStream_t stream = nullptr;
   // front end
   DevBuf pcm, n_samples, logmel, max_bits, mel_t;
+  DevBuf rec_pcm, rec_max, rec_off;   // a whole recording, the maximum of its log-mel spectrogram, window offsets (ohw_recording_set)
+  int64_t rec_n = 0;
   // encoder activations
   DevBuf c1, h, y, qkv, att, ffn, enc;
   // taps kept for diagnostics (small models / tests only)
@@ -586,6 +588,88 @@ int ohw_mel(ohw_state* st, const float* pcm, int64_t pcm_stride, const int32_t* 
     st->enc_batch = batch;
     if (mel_out) {
       HIP_CHECK(hipMemcpyAsync(mel_out, st->logmel.p, (size_t)batch * st->ctx->hp.n_mels * CHUNK_FRAMES * 4, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+    }
+  });
+}
+
+int ohw_recording_set(ohw_state* st, const float* pcm, int64_t n, int pcm_on_device, float* log_max_out) {
+  return guard([&] {
+    if (!st || !pcm || n < 1) throw Error(OHW_E_INVALID_ARG, "recording: null or empty");
+    if (n > (int64_t)7200 * 16000) throw Error(OHW_E_INVALID_ARG, "recording: more than two hours");
+    HIP_CHECK(hipSetDevice(st->ctx->device));
+    hipStream_t s = st->stream;
+    if (st->rec_pcm.bytes < (size_t)n * 4) st->rec_pcm.alloc((size_t)n * 4);
+    HIP_CHECK(hipMemcpyAsync(st->rec_pcm.p, pcm, (size_t)n * 4, pcm_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    st->rec_n = n;
+    // frames that touch a sample, in pseudo-windows of 3000; the frames of the 30 s zero tail are log10(1e-10) = -10
+    const int64_t n_audio = (n + N_FFT / 2) / HOP + 1;
+    const int chunks = (int)((n_audio + CHUNK_FRAMES - 1) / CHUNK_FRAMES);
+    const size_t need = (size_t)std::max(chunks, st->max_batch) * 8;
+    if (st->rec_off.bytes < need) st->rec_off.alloc(need);
+    if (!st->rec_max.p) st->rec_max.alloc(4);
+    std::vector<int64_t> offs((size_t)chunks);
+    for (int i = 0; i < chunks; ++i) offs[(size_t)i] = (int64_t)i * CHUNK_SAMPLES;
+    const float floor_v = -10.0f;
+    int32_t floor_bits;
+    std::memcpy(&floor_bits, &floor_v, 4);
+    floor_bits ^= 0x7fffffff;                      // the kernels' ordered-int form of a negative float
+    HIP_CHECK(hipMemcpyAsync(st->rec_max.p, &floor_bits, 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(st->rec_off.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));            // offs and floor_bits are stack-lifetime sources
+    const ohw_ctx* c = st->ctx;
+    MelParams p{};
+    p.pcm = st->rec_pcm.as<float>(); p.n_samples = st->n_samples.as<int32_t>();
+    p.filters = c->mel_filters.as<float>(); p.twiddle = c->twiddle.as<float>(); p.window = c->window.as<float>();
+    p.logmel = st->logmel.as<float>(); p.max_bits = st->rec_max.as<int32_t>(); p.mel_t = st->mel_t.p;
+    p.n_mels = c->hp.n_mels; p.batch = chunks; p.mode = OHW_MEL_ZERO_TAIL;
+    p.offsets = st->rec_off.as<int64_t>(); p.n_total = n; p.shared_max = 1; p.max_only = 1;
+    Dispatch::run(c->dtype, [&](auto* tag) {
+      using T = std::remove_pointer_t<decltype(tag)>;
+      launch_mel<T>(p, s);
+    });
+    if (log_max_out) {
+      int32_t bits = 0;
+      HIP_CHECK(hipMemcpyAsync(&bits, st->rec_max.p, 4, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      if (bits < 0) bits ^= 0x7fffffff;
+      std::memcpy(log_max_out, &bits, 4);
+    }
+  });
+}
+
+int ohw_mel_seek(ohw_state* st, const int32_t* seek_frames, int batch, float* mel_out) {
+  return guard([&] {
+    if (!st || !seek_frames) throw Error(OHW_E_INVALID_ARG, "null argument");
+    if (st->rec_n < 1) throw Error(OHW_E_INVALID_ARG, "mel_seek: no recording (ohw_recording_set)");
+    if (batch < 1 || batch > st->max_batch) throw Error(OHW_E_INVALID_ARG, "batch exceeds the state's max_batch");
+    const int64_t n_len = (st->rec_n + CHUNK_SAMPLES) / HOP;
+    std::vector<int64_t> offs((size_t)batch);
+    for (int b = 0; b < batch; ++b) {
+      if (seek_frames[b] < 0 || seek_frames[b] >= n_len) throw Error(OHW_E_INVALID_ARG, "mel_seek: seek outside the recording's frames");
+      offs[(size_t)b] = (int64_t)seek_frames[b] * HOP;
+    }
+    HIP_CHECK(hipSetDevice(st->ctx->device));
+    hipStream_t s = st->stream;
+    HIP_CHECK(hipEventRecord(st->ev[0], s));
+    HIP_CHECK(hipMemcpyAsync(st->rec_off.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    const ohw_ctx* c = st->ctx;
+    MelParams p{};
+    p.pcm = st->rec_pcm.as<float>(); p.n_samples = st->n_samples.as<int32_t>();
+    p.filters = c->mel_filters.as<float>(); p.twiddle = c->twiddle.as<float>(); p.window = c->window.as<float>();
+    p.logmel = st->logmel.as<float>(); p.max_bits = st->rec_max.as<int32_t>(); p.mel_t = st->mel_t.p;
+    p.n_mels = c->hp.n_mels; p.batch = batch; p.mode = OHW_MEL_ZERO_TAIL;
+    p.offsets = st->rec_off.as<int64_t>(); p.n_total = st->rec_n; p.shared_max = 1; p.max_only = 0;
+    Dispatch::run(c->dtype, [&](auto* tag) {
+      using T = std::remove_pointer_t<decltype(tag)>;
+      launch_mel<T>(p, s);
+    });
+    HIP_CHECK(hipEventRecord(st->ev[1], s));
+    st->mel_batch = batch;
+    st->enc_batch = batch;
+    if (mel_out) {
+      HIP_CHECK(hipMemcpyAsync(mel_out, st->logmel.p, (size_t)batch * c->hp.n_mels * CHUNK_FRAMES * 4, hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipStreamSynchronize(s));
     }
   });

@@ -320,10 +320,12 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
       const int seek_end = mel_frames(n);
       int seek = 0;
       int64_t w = 0;
+      // whisper.cpp computes the log-mel spectrogram of the whole input once (the clamp uses its global maximum) and every
+      // window reads 3000 frames of it at its seek offset
+      if (seek_end >= 100) check(ohw_recording_set(e->state, samples, n, 0, nullptr));
       while (seek_end >= 100 && seek + 100 < seek_end) {
-        const int64_t off = (int64_t)seek * HOP;
-        const int32_t ns1 = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - off);
-        check(ohw_mel(e->state, samples + off, CHUNK_SAMPLES, &ns1, 1, 0, OHW_MEL_ZERO_TAIL, nullptr));
+        const int32_t seek32 = seek;
+        check(ohw_mel_seek(e->state, &seek32, 1, nullptr));      // 3000 frames of the recording-wide spectrogram
         check(ohw_encode(e->state, 1));
         greedy_t0(sc, e->state, 1, &seek, &seek_end, w);
         run_ladder(sc, e->state, 1, &seek, &seek_end, w, rngs.v);

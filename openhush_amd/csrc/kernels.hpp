@@ -32,6 +32,13 @@ struct MelParams {
   int32_t* max_bits;        // device [batch] ordered-int running max
   void* mel_t;              // device T [batch][3002][128] time-major image for conv1
   int32_t n_mels, batch, mode;
+  // windows of a whole recording's spectrogram (ohw_recording_set / ohw_mel_seek): pcm is the recording (n_total samples),
+  // window b starts at sample offsets[b] of it - real neighbouring samples at its edges, the reflection only at the
+  // recording's start, zeros after its end; shared_max: ONE running maximum, max_bits[0], for all windows;
+  // max_only: no spectrogram is stored (the pass that finds the recording's maximum)
+  const int64_t* offsets = nullptr;
+  int64_t n_total = 0;
+  int32_t shared_max = 0, max_only = 0;
 };
 template <typename T> void launch_mel(const MelParams& p, hipStream_t s);
 

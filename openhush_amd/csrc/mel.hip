@@ -29,8 +29,10 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_power_kernel(MelParams p) {
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * MEL_FR;
   const int tid = threadIdx.x;
-  const int64_t n = p.n_samples[b] < CHUNK_SAMPLES ? p.n_samples[b] : CHUNK_SAMPLES;
-  const float* pcm = p.pcm + (int64_t)b * p.pcm_stride;
+  const bool rec = p.offsets != nullptr;
+  const int64_t off = rec ? p.offsets[b] : 0;
+  const int64_t n = rec ? p.n_total : (p.n_samples[b] < CHUNK_SAMPLES ? p.n_samples[b] : CHUNK_SAMPLES);
+  const float* pcm = rec ? p.pcm : p.pcm + (int64_t)b * p.pcm_stride;
   for (int i = tid; i < N_FFT; i += MEL_THREADS) { tw[0][i] = p.twiddle[i]; tw[1][i] = p.twiddle[N_FFT + i]; }
   for (int i = tid; i < N_FFT * MEL_FR; i += MEL_THREADS) {
     const int f = i / N_FFT, j = i % N_FFT;
@@ -38,8 +40,13 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_power_kernel(MelParams p) {
     int64_t pos = (int64_t)t * HOP - N_FFT / 2 + j;   // index into the zero-padded 30 s signal
     float v = 0.0f;
     if (t < CHUNK_FRAMES) {
-      if (pos < 0) pos = -pos;                                            // reflect at the start
-      else if (pos >= CHUNK_SAMPLES) pos = p.mode == OHW_MEL_REFLECT ? 2 * (int64_t)(CHUNK_SAMPLES - 1) - pos : -1;
+      if (rec) {
+        pos += off;                                                       // index into the recording
+        if (pos < 0) pos = -pos;                                          // reflected only at the recording's start
+      } else {
+        if (pos < 0) pos = -pos;                                          // reflect at the start
+        else if (pos >= CHUNK_SAMPLES) pos = p.mode == OHW_MEL_REFLECT ? 2 * (int64_t)(CHUNK_SAMPLES - 1) - pos : -1;
+      }
       if (pos >= 0 && pos < n) v = pcm[pos];
     }
     fr[j][f] = v * p.window[j];
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_power_kernel(MelParams p) {
     float acc = 0.f;
     for (int k = 0; k < N_FREQ; ++k) acc += fj[k] * pw[f][k];
     const float lv = log10f(fmaxf(acc, 1e-10f));
-    p.logmel[((int64_t)b * p.n_mels + j) * CHUNK_FRAMES + t] = lv;
+    if (!p.max_only) p.logmel[((int64_t)b * p.n_mels + j) * CHUNK_FRAMES + t] = lv;
     lmax = fmaxf(lmax, lv);
   }
   lmax = wave_max(lmax);
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_power_kernel(MelParams p) {
   if (tid == 0) {
     float m = red[0];
     for (int i = 1; i < MEL_THREADS / 64; ++i) m = fmaxf(m, red[i]);
-    if (m > -INFINITY) atomicMax(&p.max_bits[b], ordered_bits(m));
+    if (m > -INFINITY) atomicMax(&p.max_bits[p.shared_max ? 0 : b], ordered_bits(m));
   }
 }
 
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(256) void mel_normalize_kernel(MelParams p) {
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
-  const float mx = from_ordered_bits(p.max_bits[b]);
+  const float mx = from_ordered_bits(p.max_bits[p.shared_max ? 0 : b]);
   const float floor_v = mx - 8.0f;
   for (int i = tid; i < p.n_mels * 64; i += 256) {
     const int c = i / 64, tt = i % 64;
@@ -121,9 +128,9 @@ __global__ __launch_bounds__(256) void mel_normalize_kernel(MelParams p) {
 
 template <typename T>
 void launch_mel(const MelParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(mel_init_kernel, dim3((p.batch + 63) / 64), dim3(64), 0, s, p.max_bits, p.batch);
+  if (!p.shared_max) hipLaunchKernelGGL(mel_init_kernel, dim3((p.batch + 63) / 64), dim3(64), 0, s, p.max_bits, p.batch);
   hipLaunchKernelGGL(mel_power_kernel, dim3((CHUNK_FRAMES + MEL_FR - 1) / MEL_FR, p.batch), dim3(MEL_THREADS), 0, s, p);
-  hipLaunchKernelGGL((mel_normalize_kernel<T>), dim3((CHUNK_FRAMES + 63) / 64, p.batch), dim3(256), 0, s, p);
+  if (!p.max_only) hipLaunchKernelGGL((mel_normalize_kernel<T>), dim3((CHUNK_FRAMES + 63) / 64, p.batch), dim3(256), 0, s, p);
   HIP_CHECK(hipGetLastError());
 }
 template void launch_mel<bf16_t>(const MelParams&, hipStream_t);

@@ -113,7 +113,7 @@ AUDIO_ERRORS = {0: "Ok", 1: "Empty", 2: "InvalidSampleRate", 3: "TooLong", 4: "T
 # every symbol include/ohw.h declares
 EXPORTS = [
     "ohw_validate_audio", "ohw_ctx_create", "ohw_ctx_create_synthetic", "ohw_ctx_info", "ohw_token_text", "ohw_ctx_free",
-    "ohw_state_create", "ohw_state_free", "ohw_state_set_stream", "ohw_state_max_batch", "ohw_mel", "ohw_encode", "ohw_decode",
+    "ohw_state_create", "ohw_state_free", "ohw_state_set_stream", "ohw_state_max_batch", "ohw_mel", "ohw_recording_set", "ohw_mel_seek", "ohw_encode", "ohw_decode",
     "ohw_default_sample_params", "ohw_sample_greedy_host", "ohw_greedy", "ohw_state_timings", "ohw_engine_new",
     "ohw_engine_transcribe", "ohw_engine_last_tokens", "ohw_engine_benchmark", "ohw_engine_free", "ohw_engine_state",
     "ohw_engine_ctx", "ohw_lang_id_to_code", "ohw_lang_code_to_id", "ohw_last_error", "ohw_abi_version", "ohw_state_fetch",
@@ -230,6 +230,8 @@ def lib():
         L.ohw_stream_sync.argtypes = [vp]
         L.ohw_state_max_batch.argtypes = [vp]
         L.ohw_mel.argtypes = [vp, vp, C.c_int64, ip, C.c_int, C.c_int, C.c_int, fp]
+        L.ohw_recording_set.argtypes = [vp, vp, C.c_int64, C.c_int, fp]
+        L.ohw_mel_seek.argtypes = [vp, ip, C.c_int, fp]
         L.ohw_encode.argtypes = [vp, C.c_int]
         L.ohw_encode_slice.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.ohw_detect_language.argtypes = [vp, C.c_int, ip, fp]
@@ -513,6 +515,20 @@ class State:
         """pcm already resident in HBM (e.g. a torch tensor's data_ptr())"""
         ns = np.asarray(n_samples, dtype=np.int32)
         _check(lib().ohw_mel(self.h, C.c_void_p(pcm_ptr), stride, _ip(ns), len(ns), 1, mode, C.cast(None, C.POINTER(C.c_float))))
+
+    def recording_set(self, pcm: np.ndarray) -> float:
+        """ohw_recording_set: the whole recording into the state -> log10 of the largest mel power over all its frames"""
+        x = np.ascontiguousarray(pcm, dtype=np.float32)
+        mx = C.c_float(0.0)
+        _check(lib().ohw_recording_set(self.h, x.ctypes.data_as(C.c_void_p), x.size, 0, C.byref(mx)))
+        return float(mx.value)
+
+    def mel_seek(self, seek_frames: Sequence[int], want: bool = True):
+        """ohw_mel_seek: windows [seek, seek + 3000) of the recording-wide spectrogram -> [B][n_mels][3000] (or None)"""
+        sk = np.asarray(seek_frames, dtype=np.int32)
+        out = np.empty((len(sk), self.ctx.hp.n_mels, CHUNK_FRAMES), dtype=np.float32) if want else None
+        _check(lib().ohw_mel_seek(self.h, _ip(sk), len(sk), _fp(out) if want else C.cast(None, C.POINTER(C.c_float))))
+        return out
 
     def encode(self, batch: int):
         _check(lib().ohw_encode(self.h, batch))

@@ -95,6 +95,9 @@ def lib():
         L.ref_model_n_langs.argtypes = [C.c_void_p]
         L.ref_validate_audio.argtypes = [fp, C.c_int64, C.c_uint32, C.POINTER(AudioInfo)]
         L.ref_log_mel.argtypes = [C.c_void_p, fp, C.c_int64, C.c_int, fp]
+        L.ref_log_mel_recording_max.argtypes = [C.c_void_p, fp, C.c_int64]
+        L.ref_log_mel_recording_max.restype = C.c_double
+        L.ref_log_mel_seek.argtypes = [C.c_void_p, fp, C.c_int64, C.c_int64, C.c_double, fp]
         L.ref_encode.argtypes = [C.c_void_p, fp, fp, fp, fp, fp]
         L.ref_state_new.restype = C.c_void_p
         L.ref_state_new.argtypes = [C.c_void_p]
@@ -210,6 +213,20 @@ class Model:
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
         out = np.empty((self.n_mels, CHUNK_FRAMES), dtype=np.float32)
         lib().ref_log_mel(self.h, _fp(pcm), pcm.size, mode, _fp(out))
+        return out
+
+    def recording_max(self, pcm: np.ndarray) -> float:
+        """maximum of log10 mel power over every frame of the recording (whisper.cpp's whole-input clamp, as recalled)"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        return float(lib().ref_log_mel_recording_max(self.h, _fp(pcm), pcm.size))
+
+    def log_mel_seek(self, pcm: np.ndarray, seek: int, rec_max: Optional[float] = None) -> np.ndarray:
+        """frames [seek, seek + 3000) of the recording-wide spectrogram, clamped with the recording's maximum"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        if rec_max is None:
+            rec_max = self.recording_max(pcm)
+        out = np.empty((self.n_mels, CHUNK_FRAMES), dtype=np.float32)
+        lib().ref_log_mel_seek(self.h, _fp(pcm), pcm.size, int(seek), float(rec_max), _fp(out))
         return out
 
     def encode(self, mel: np.ndarray, taps: bool = False):

@@ -364,6 +364,43 @@ def test_batch_invariant_decode_is_independent_of_the_batch(E, models):
             assert a["tokens"] == b["tokens"] and np.array_equal(a["logprobs"], b["logprobs"]), B
 
 
+def test_mel_seek_windows_of_the_recording_wide_spectrogram(E, models):
+    """ohw_recording_set / ohw_mel_seek against the oracle's restatement of whisper.cpp's whole-input front end (as recalled,
+    unpinned): the clamp uses the maximum over all frames of the recording, a window's edges see the real neighbouring
+    samples, zeros only follow the recording's end.  A recording of one window at seek 0 is ohw_mel's zero-tail mode."""
+    _, _, om, ctxs = models
+    st = E.State(ctxs[1], 3)
+    with pytest.raises(E.WhisperError):
+        st.mel_seek([0])                                     # no recording yet
+    rec = np.concatenate([0.05 * synth.synth_audio(21), synth.synth_audio(22), 0.2 * synth.synth_audio(23, 150000)]).astype(np.float32)
+    gmax = st.recording_set(rec)
+    ref_max = om.recording_max(rec)
+    assert abs(gmax - ref_max) < 1e-4
+    n_len = (len(rec) + 480000) // 160
+    seeks = [0, 1234, 4700]                                  # the first (quiet) window, across the loud part, into the zero tail
+    got = st.mel_seek(seeks)
+    for b, sk in enumerate(seeks):
+        ref = om.log_mel_seek(rec, sk, ref_max)
+        assert np.abs(got[b] - ref).max() < 2e-4, (sk, float(np.abs(got[b] - ref).max()))
+    assert np.abs(got[0] - om.log_mel(rec[:480000], 1)).max() > 0.5        # the quiet window alone would clamp 2.6 lower
+    with pytest.raises(E.WhisperError):
+        st.mel_seek([n_len])                                 # past the recording's frames
+    with pytest.raises(E.WhisperError):
+        st.mel_seek([0, 1, 2, 3])                            # more windows than the state holds
+    # the encoder consumes the windows like ohw_mel's
+    st.encode(3)
+    enc = st.fetch("enc", 3)
+    ref_enc = om.encode(om.log_mel_seek(rec, 1234, ref_max))
+    assert np.abs(enc[1] - ref_enc).max() < 2 * TOL_ACT[1]
+    # a short recording: seek 0 IS the per-window zero-tail spectrogram (same kernel arithmetic, bit for bit)
+    short = synth.synth_audio(7, 300000)
+    st.recording_set(short)
+    a = st.mel_seek([0])[0]
+    b = st.mel(short[None, :], [len(short)], E.OHW_MEL_ZERO_TAIL)[0]
+    assert np.array_equal(a, b)
+    st.close()
+
+
 def test_cu_masked_streams_give_the_same_tokens(E, models):
     """ohw_stream_create / _wait / _sync (include/ohw.h): the front end on a 96-CU stream, the decode on the other 160 CUs
     (fewer CUs change which kernel variants run, never the result beyond fp32 re-association: same greedy tokens on this

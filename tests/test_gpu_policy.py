@@ -82,7 +82,7 @@ def test_host_temperature_sampler_matches_oracle_draw_for_draw(E, oracle):
     assert tok0 == rt and abs(lp0 - rlp) < 2e-4 and abs(nsp - rns) < 1e-6
 
 
-def _walk_and_compare(E, oracle, om, eng, windows_pcm, bias, pol, seeks=None, ends=None, mode=0, n_max=220):
+def _walk_and_compare(E, oracle, om, eng, windows_pcm, bias, pol, seeks=None, ends=None, mode=0, n_max=220, mels=None):
     """Replays every pass of the engine's trace on the oracle; returns (passes compared, steps, steps where the oracle's own
     pick equals the engine's token)."""
     trace = eng.last_trace()
@@ -98,7 +98,7 @@ def _walk_and_compare(E, oracle, om, eng, windows_pcm, bias, pol, seeks=None, en
     kept_all = []
     for w in sorted(by_win):
         s = oracle.State(om)
-        s.set_encoder_output(om.encode(om.log_mel(windows_pcm[w], 1)))
+        s.set_encoder_output(om.encode(mels[w] if mels is not None else om.log_mel(windows_pcm[w], 1)))
         rng = shared_rng if mode == 1 else oracle.MT19937(0)
         seek = seeks[w] if seeks else 0
         end = ends[w] if ends else oracle.mel_frames(len(windows_pcm[w]))
@@ -212,12 +212,13 @@ def test_short_tail_and_sub_second_input_yield_nothing(E, tmp_models):
 def test_seek_loop_with_timestamps_matches_oracle(E, oracle, tmp_models):
     """OHW_WINDOW_SEEK with a bias that makes the model emit timestamps: windows advance by 2 * (last timestamp - begin)
     frames (not 3000), the tokens after the last timestamp are dropped and decoded again by the next window; one generator
-    for the whole call.  Every pass of every window is replayed on the oracle."""
+    for the whole call; the windows are cut from the spectrogram of the WHOLE recording (ohw_recording_set / ohw_mel_seek).  Every pass of every window is replayed on the oracle."""
     import ctypes as C
     path = tmp_models("micro")
     om = oracle.Model.load(path)
     bias = _bias(om, 8.0, 26.0)
-    pcm = np.concatenate([synth.synth_audio(41), synth.synth_audio(42, 200000)])
+    # the tail 20 dB quieter: its own maximum would clamp 2.0 lower than the recording's, which the seek mode uses
+    pcm = np.concatenate([synth.synth_audio(41), 0.1 * synth.synth_audio(42, 200000)]).astype(np.float32)
     eng = E.WhisperEngine.new(path, "en", False, True, 0, E.OHW_DTYPE_F16, 1)
     eng.set_window_mode(E.OHW_WINDOW_SEEK)
     E.lib().ohw_state_set_logit_bias(E.lib().ohw_engine_state(eng.h), bias.ctypes.data_as(C.POINTER(C.c_float)), bias.size)
@@ -233,7 +234,11 @@ def test_seek_loop_with_timestamps_matches_oracle(E, oracle, tmp_models):
         seek += x["seek_delta"] if x["seek_delta"] > 0 else 3000
     assert seek + 100 >= seek_end and len(q) >= 2                   # the loop ran to the end of the audio
     assert any(x["seek_delta"] != 3000 for x in q)                  # timestamps really drove the seek
-    n_pass, n_steps, n_same = _walk_and_compare(E, oracle, om, eng, wins, bias, pol, seeks=seeks, ends=[seek_end] * len(q), mode=1)
+    # the oracle's windows: frames [seek, seek + 3000) of the recording-wide spectrogram (global clamp, real neighbours)
+    rec_max = om.recording_max(pcm)
+    mels = [om.log_mel_seek(pcm, sk, rec_max) for sk in seeks]
+    assert any(np.abs(mels[i] - om.log_mel(wins[i], 1)).max() > 0.1 for i in range(1, len(seeks)))    # it matters here
+    n_pass, n_steps, n_same = _walk_and_compare(E, oracle, om, eng, wins, bias, pol, seeks=seeks, ends=[seek_end] * len(q), mode=1, mels=mels)
     print(f"seek loop: {len(q)} windows, seek deltas {[x['seek_delta'] for x in q]}, {n_pass} passes, {n_same} / {n_steps} steps identical")
     assert n_same >= 0.98 * n_steps
     eng.close()

@@ -28,7 +28,11 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     a = ap.parse_args()
     ctx = E.Context.synthetic(synth.PRESETS[a.model].as_list(), 1234, 0, E.OHW_DTYPE_BF16 if a.dtype == "bf16" else E.OHW_DTYPE_F16)
-    p = ctx.default_params(); p.force_len = a.tokens
+    p = ctx.default_params()
+    if a.beam >= 2:
+        p.n_max = a.tokens          # beams end at n_max (force_len is the greedy loop's knob)
+    else:
+        p.force_len = a.tokens
     n = int(a.chunk * 16000)
     rec = np.concatenate([synth.synth_audio(40 + i)[:n] for i in range(a.chunks)])
     vad = E.EnergyVad(-40.0)
