@@ -362,8 +362,11 @@ int ohw_engine_last_trace(ohw_engine* e, const int32_t** data, int* n);
  * (BASELINE.json north_star).  SEEK: whisper.cpp's sequential loop as recalled (unpinned): the
  * next window starts at the last timestamp token of the previous one (seek += 2 * (ts - ts_begin) frames of
  * 10 ms, or 3000 when no timestamp was produced), tokens after that timestamp are dropped and re-decoded;
- * stops when less than 1 s is left.  One window at a time, so batch = 1. */
-enum { OHW_WINDOW_FIXED = 0, OHW_WINDOW_SEEK = 1 };
+ * stops when less than 1 s is left.  One window at a time, so batch = 1.
+ * FIXED_RECORDING_MEL: the cuts, batching and schedules of FIXED, but every window is cut from the spectrogram of the WHOLE
+ * recording (ohw_recording_set / ohw_mel_seek): one clamp maximum for all windows and real samples across the 30 s marks -
+ * what whisper.cpp's front end gives a recording handed over in one call - instead of treating each cut as its own call. */
+enum { OHW_WINDOW_FIXED = 0, OHW_WINDOW_SEEK = 1, OHW_WINDOW_FIXED_RECORDING_MEL = 2 };
 int ohw_engine_set_window_mode(ohw_engine* e, int mode);
 /* How audio of more than max_batch windows is overlapped on the device (the reference transcribes one buffer at a time,
  * src/queue/worker.rs:100-160; results are identical under every schedule):

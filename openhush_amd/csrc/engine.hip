@@ -551,6 +551,24 @@ int ohw_state_max_batch(const ohw_state* st) { return st ? st->max_batch : 0; }
 }  // extern "C"
 namespace ohw {
 // the state's logit bias as the host sampler needs it (null when none is set); library-internal
+// dst reads src's recording (no copy: a view of its samples) and gets its maximum; same device; dst must not outlive src's
+// recording (the engine shares among its own states for the length of one transcribe)
+void state_share_recording(ohw_state* dst, ohw_state* src) {
+  if (!dst || !src || dst == src) return;
+  if (src->rec_n < 1) throw Error(OHW_E_INVALID_ARG, "share_recording: the source state holds no recording");
+  HIP_CHECK(hipSetDevice(src->ctx->device));
+  HIP_CHECK(hipStreamSynchronize(src->stream));                 // the maximum is final
+  dst->rec_pcm.view(src->rec_pcm.p, src->rec_pcm.bytes);
+  dst->rec_n = src->rec_n;
+  if (!dst->rec_max.p) dst->rec_max.alloc(4);
+  if (dst->rec_off.bytes < (size_t)dst->max_batch * 8) dst->rec_off.alloc((size_t)dst->max_batch * 8);
+  HIP_CHECK(hipMemcpy(dst->rec_max.p, src->rec_max.p, 4, hipMemcpyDeviceToDevice));
+}
+void state_drop_recording(ohw_state* st) {
+  if (!st || st->rec_pcm.owned) return;
+  st->rec_pcm.release();          // a view: nothing is freed
+  st->rec_n = 0;
+}
 const float* state_bias_host(const ohw_state* st) { return st && st->bias_on && !st->bias_host.empty() ? st->bias_host.data() : nullptr; }
 }
 extern "C" {

@@ -25,6 +25,8 @@
 namespace ohw {
 extern thread_local std::string g_last_error;
 const float* state_bias_host(const ohw_state* st);
+void state_share_recording(ohw_state* dst, ohw_state* src);
+void state_drop_recording(ohw_state* st);
 }
 extern "C" const ohw_ctx* ohw_state_ctx(const ohw_state* st);
 using namespace ohw;
@@ -341,6 +343,16 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
       const int64_t n_win = (n + CHUNK_SAMPLES - 1) / CHUNK_SAMPLES;
       const int64_t n_batches = (n_win + e->max_batch - 1) / e->max_batch;
       auto batch_of = [&](int64_t bi) { return (int)std::min<int64_t>(e->max_batch, n_win - bi * e->max_batch); };
+      // windows w0 .. w0 + B of the recording into st: each cut on its own (its own `full()` call), or cut from the spectrogram
+      // of the whole recording (FIXED_RECORDING_MEL: st reads the recording e->state holds)
+      const bool rec_mel = e->window_mode == OHW_WINDOW_FIXED_RECORDING_MEL;
+      auto mel_windows = [&](ohw_state* st, int64_t w0, int B, const int32_t* nsv) {
+        if (!rec_mel) { check(ohw_mel(st, samples + w0 * CHUNK_SAMPLES, CHUNK_SAMPLES, nsv, B, 0, OHW_MEL_ZERO_TAIL, nullptr)); return; }
+        std::vector<int32_t> seeks((size_t)B);
+        for (int b = 0; b < B; ++b) seeks[(size_t)b] = (int32_t)((w0 + b) * CHUNK_FRAMES);
+        check(ohw_mel_seek(st, seeks.data(), B, nullptr));
+      };
+      if (rec_mel) check(ohw_recording_set(e->state, samples, n, 0, nullptr));
       auto fill_ns = [&](int64_t bi, std::vector<int32_t>& nsv) {
         const int64_t w0 = bi * e->max_batch;
         const int B = batch_of(bi);
@@ -349,7 +361,7 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
       auto front = [&](int64_t bi, ohw_state* st, void* stream, std::vector<int32_t>& nsv) {
         fill_ns(bi, nsv);
         check(ohw_state_set_stream(st, stream));
-        check(ohw_mel(st, samples + bi * e->max_batch * CHUNK_SAMPLES, CHUNK_SAMPLES, nsv.data(), batch_of(bi), 0, OHW_MEL_ZERO_TAIL, nullptr));
+        mel_windows(st, bi * e->max_batch, batch_of(bi), nsv.data());
         check(ohw_encode(st, batch_of(bi)));
       };
       // the decode of one batch on whatever stream the state is set to; fills sc.runs (and sc.trace); re-entrant per Scratch
@@ -446,6 +458,19 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
         Invariant(ohw_engine* e_, bool on_) : e(e_), on(on_) { if (on) set(true); }
         ~Invariant() { if (on) set(false); }
       } invariant(e, n_batches > 1);
+      struct SharedRecording {      // every state of this transcribe reads the recording e->state holds
+        ohw_engine* e; bool on;
+        SharedRecording(ohw_engine* e_, bool on_) : e(e_), on(on_) {
+          if (!on) return;
+          for (ohw_state* st : e->states) state_share_recording(st, e->state);
+          for (ohw_state* st : e->lane_states) state_share_recording(st, e->state);
+        }
+        ~SharedRecording() {
+          if (!on) return;
+          for (ohw_state* st : e->states) if (st != e->state) state_drop_recording(st);
+          for (ohw_state* st : e->lane_states) state_drop_recording(st);
+        }
+      } shared_recording(e, rec_mel);
       auto restore = [&] {
         for (ohw_state* st : e->states) (void)ohw_state_set_stream(st, nullptr);
         for (ohw_state* st : e->lane_states) (void)ohw_state_set_stream(st, nullptr);
@@ -456,7 +481,7 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
         std::vector<int32_t> ns((size_t)e->max_batch);
         for (int64_t bi = 0; bi < n_batches; ++bi) {
           fill_ns(bi, ns);
-          check(ohw_mel(e->state, samples + bi * e->max_batch * CHUNK_SAMPLES, CHUNK_SAMPLES, ns.data(), batch_of(bi), 0, OHW_MEL_ZERO_TAIL, nullptr));
+          mel_windows(e->state, bi * e->max_batch, batch_of(bi), ns.data());
           check(ohw_encode(e->state, batch_of(bi)));
           decode_batch(sc, e->state, bi, ns.data());
           collect(sc, batch_of(bi));
@@ -526,7 +551,7 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
               for (int f = 0; f < Wd; f += e->max_batch) {
                 const int Bf = std::min(e->max_batch, Wd - f);
                 for (int b = 0; b < Bf; ++b) nss[(size_t)j][(size_t)(f + b)] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + f + b) * CHUNK_SAMPLES);
-                check(ohw_mel(st, samples + (w0 + f) * CHUNK_SAMPLES, CHUNK_SAMPLES, &nss[(size_t)j][(size_t)f], Bf, 0, OHW_MEL_ZERO_TAIL, nullptr));
+                mel_windows(st, w0 + f, Bf, &nss[(size_t)j][(size_t)f]);
                 check(ohw_encode_slice(st, Bf, f, Wd));
               }
             }
@@ -537,6 +562,9 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
             }
             std::vector<std::string> errs((size_t)grp);
             std::vector<std::thread> th;
+            // the host waits for the group's front ends before the lane threads start: lanes that begin to enqueue their
+            // decode while the front ends still run cost 6 % of a step in bench.py (283.9 against 262 - 268 ms)
+            check(ohw_stream_sync(e->s_full));
             for (int j = 0; j < grp; ++j) {
               check(ohw_stream_wait(e->lane_streams[(size_t)j], e->s_full));
               check(ohw_state_set_stream(e->lane_states[(size_t)j], e->lane_streams[(size_t)j]));
@@ -858,7 +886,7 @@ int ohw_engine_set_schedule(ohw_engine* e, int schedule, int lanes, int merge) {
 }
 
 int ohw_engine_set_window_mode(ohw_engine* e, int mode) {
-  if (!e || (mode != OHW_WINDOW_FIXED && mode != OHW_WINDOW_SEEK)) return OHW_E_INVALID_ARG;
+  if (!e || (mode != OHW_WINDOW_FIXED && mode != OHW_WINDOW_SEEK && mode != OHW_WINDOW_FIXED_RECORDING_MEL)) return OHW_E_INVALID_ARG;
   e->window_mode = mode;
   return OHW_OK;
 }

@@ -27,7 +27,7 @@ CHUNK_FRAMES = 3000
 
 OHW_DTYPE_AUTO, OHW_DTYPE_BF16, OHW_DTYPE_F16 = -1, 0, 1
 OHW_MEL_REFLECT, OHW_MEL_ZERO_TAIL = 0, 1
-OHW_WINDOW_FIXED, OHW_WINDOW_SEEK = 0, 1
+OHW_WINDOW_FIXED, OHW_WINDOW_SEEK, OHW_WINDOW_FIXED_RECORDING_MEL = 0, 1, 2
 OHW_SCHEDULE_SEQUENTIAL, OHW_SCHEDULE_PIPELINE, OHW_SCHEDULE_LANES = 0, 1, 2
 EPI_BIAS_T, EPI_BIAS_GELU_T, EPI_BIAS_RESID_F32, EPI_F32 = 0, 1, 2, 4
 
@@ -937,7 +937,8 @@ class WhisperEngine:
         return out
 
     def set_window_mode(self, mode: int):
-        """OHW_WINDOW_FIXED (0, default) or OHW_WINDOW_SEEK (1, whisper.cpp's timestamp-driven loop)"""
+        """OHW_WINDOW_FIXED (0, default), OHW_WINDOW_SEEK (1, whisper.cpp's timestamp-driven loop) or OHW_WINDOW_FIXED_RECORDING_MEL
+        (2: fixed cuts taken from the spectrogram of the whole recording)"""
         _check(lib().ohw_engine_set_window_mode(self.h, mode))
 
     def set_schedule(self, schedule: int, lanes: int = 0, merge: int = 0):

@@ -271,3 +271,31 @@ def test_pool_behind_the_c_abi(E, tmp_models):
         E.EnginePool(path + ".missing", "auto", False, [0])
     with pytest.raises(E.WhisperError):
         E.EnginePool(path, "auto", False, [0, 7])           # no such device on this box
+
+
+def test_fixed_cuts_on_the_recording_wide_spectrogram(E, oracle, tmp_models):
+    """OHW_WINDOW_FIXED_RECORDING_MEL: the batched fixed-cut path (two batches here: the LANES schedule, states sharing one
+    recording) on windows cut from the spectrogram of the whole recording - a quiet first window gets the loud file's clamp.
+    Every pass of every window is replayed on the oracle's ref_log_mel_seek windows."""
+    path = tmp_models("micro")
+    om = oracle.Model.load(path)
+    pcm = np.concatenate([0.05 * synth.synth_audio(51), synth.synth_audio(52), 0.3 * synth.synth_audio(53, 250000)]).astype(np.float32)
+    wins = [pcm[w * 480000:(w + 1) * 480000] for w in range(3)]
+    rec_max = om.recording_max(pcm)
+    mels = [om.log_mel_seek(pcm, w * 3000, rec_max) for w in range(3)]
+    assert np.abs(mels[0] - om.log_mel(wins[0], 1)).max() > 0.5           # the quiet window alone clamps 2.6 lower
+    pol = oracle.default_policy()
+    out = {}
+    for mode in (E.OHW_WINDOW_FIXED_RECORDING_MEL, E.OHW_WINDOW_FIXED):
+        eng = E.WhisperEngine.new(path, "en", False, True, 0, E.OHW_DTYPE_F16, 2)
+        eng.set_window_mode(mode)
+        eng.transcribe(E.AudioBuffer(pcm, 16000))
+        out[mode] = eng.last_trace()
+        if mode == E.OHW_WINDOW_FIXED_RECORDING_MEL:
+            n_pass, n_steps, n_same = _walk_and_compare(E, oracle, om, eng, wins, None, pol, mels=mels)
+            print(f"fixed cuts, recording-wide mel: {n_pass} passes, {n_same} / {n_steps} steps identical")
+            assert n_same >= 0.98 * n_steps
+            again = eng.transcribe(E.AudioBuffer(pcm[:480000 * 2], 16000))          # another recording through the same states
+            assert len(eng.last_quality_ex()) == 2 and again is not None
+        eng.close()
+    assert out[E.OHW_WINDOW_FIXED_RECORDING_MEL] != out[E.OHW_WINDOW_FIXED]          # the clamp changes what window 0 decodes to
