@@ -944,6 +944,17 @@ void launch_cross_attn(const void* q, const void* xk, const void* xv, void* out,
   // (window, head) streams it once for all of them (done: per window)
   if (kv_group > 1) {
     if (n_new != 1 || M % kv_group != 0 || kv_group > 5) throw Error(OHW_E_INVALID_ARG, "cross-attention: beams are single-token rows, at most 5 per window");
+    // a few windows (streaming: ONE): n_head workgroups would each pull a 384-KB stream alone (48.6 us per launch at one
+    // window, half of the beam step); the general kernel with n_new = kv_group reads window m / kv_group for row m and
+    // cuts the keys of every (row, head) over up to 8 workgroups instead (the K/V bytes are a few MB here)
+    if (!batch_invariant && partials && tickets && M <= max_split_rows && (int64_t)(M / kv_group) * n_head < 128) {
+      int ks = 1;
+      while (ks < XA_MAX_SPLIT && (int64_t)M * n_head * ks < 512 && t_len / (ks * 2) >= 64) ks *= 2;
+      hipLaunchKernelGGL((cross_attn_kernel<T>), dim3(n_head, M, ks), dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, kv_group,
+                         n_head, t_len, partials, tickets, done);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     const dim3 grid(n_head, M / kv_group);
     switch (kv_group) {
       case 2: hipLaunchKernelGGL((cross_attn_rows_kernel<T, 2>), grid, dim3(XA_THREADS), 0, s, (const T*)q, (const T*)xk, (const T*)xv, (T*)out, n_head, t_len, done); break;

@@ -189,6 +189,7 @@ void state_alloc(ohw_state* st) {
   // post-norm decoder GEMMs (decode.hip): OHW_DEC_POSTNORM=1 (off by default: measured, no gain - the LayerNorm prologue
   // already hides under the weights' first-byte latency); never with a split-K knob (the split path
   // publishes no statistics); dt must be a multiple of 32
+  st->graphs_enabled = env_int("OHW_GRAPHS", 1, 0, 1) != 0;      // 0: the decode iterations are launched kernel by kernel (diagnostics)
   st->postnorm = env_int("OHW_DEC_POSTNORM", 0, 0, 1) != 0 && dec_ksplit_long() == 1 && dec_ksplit_short() == 1 && dt % 32 == 0;
   st->dx16.alloc(m_tiles * dt * 2, true);
   st->xstat.alloc((size_t)st->m_max * (dt / 16) * 2 * 4, true);
