@@ -127,6 +127,20 @@ int64_t ohw_dsp_resample_linear(const float* in, int64_t n, uint32_t from_rate, 
  * unpinned.  Same size-query convention as ohw_dsp_resample_linear.                                                  */
 int64_t ohw_dsp_resample_sinc(const float* in, int64_t n, uint32_t from_rate, uint32_t to_rate, float* out, int64_t out_cap);
 
+/* the same resampler on the device (resample.hip): every output sample is independent, so a recording that lies in HBM - or
+ * goes there for the log-mel anyway - is resampled there (one wave per output sample; 30 s at 48 kHz in a fraction of a
+ * millisecond).  Same number of samples as ohw_dsp_resample_sinc and, up to the order of the fp32 sums, the same samples.
+ *   ohw_resampler_create     builds the 256 x 256 polyphase table for from_rate -> to_rate on `device`;
+ *   ohw_resampler_out_len    output samples for n input samples;
+ *   ohw_resampler_run        in / out in host or device memory (in_on_device / out_on_device), on hip_stream (NULL = the
+ *                            default stream); returns when host buffers may be reused, asynchronous when both are device. */
+typedef struct ohw_resampler ohw_resampler;
+int ohw_resampler_create(int device, uint32_t from_rate, uint32_t to_rate, ohw_resampler** out);
+void ohw_resampler_free(ohw_resampler* r);
+int64_t ohw_resampler_out_len(const ohw_resampler* r, int64_t n);
+int ohw_resampler_run(ohw_resampler* r, const float* in, int64_t n, int in_on_device, float* out, int64_t out_cap, int out_on_device,
+                      void* hip_stream);
+
 /* ---- voice-activity segmentation, the step in front of the path in continuous mode (host code) --------
  *      ohw_vad_state_*: the reference's VadState (src/vad/mod.rs:112-250) - per-chunk VAD results in, speech segments out;
  *      ohw_vad_engine: its VadEngine trait (src/vad/mod.rs:34-55) as a struct of function pointers, so the host plugs in the

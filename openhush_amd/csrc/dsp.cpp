@@ -108,29 +108,64 @@ int64_t ohw_dsp_resample_linear(const float* in, int64_t n, uint32_t from_rate, 
 //            -sinc_len / 2 and advances by 1 / ratio per output; an output is the linear blend (weight = fractional part of
 //            idx * F) of the dot products of the sinc_len inputs starting at floor(idx) with the two nearest sub-filters;
 //            a chunk's outputs stop at idx >= chunk - (sinc_len + 1) - ceil(1 / ratio); idx -= chunk for the next call.
+}  // extern "C"
+
+namespace ohw {
+// the polyphase table [F = 256 sub-filters][L = 256 taps] of the sinc resampler for an output / input rate ratio (shared with
+// the device resampler, resample.hip)
+void sinc_table(double r, std::vector<float>& sincs) {
+  constexpr int L = 256, F = 256;
+  sincs.assign((size_t)F * L, 0.0f);
+  const double fc = r >= 1.0 ? 0.95 : 0.95 * r;
+  const int T = L * F;
+  std::vector<double> y((size_t)T);
+  double sum = 0.0;
+  const double PI = 3.14159265358979323846;
+  for (int x = 0; x < T; ++x) {
+    const double xf = (double)x / (double)T;
+    const double bh = 0.35875 - 0.48829 * std::cos(2.0 * PI * xf) + 0.14128 * std::cos(4.0 * PI * xf) - 0.01168 * std::cos(6.0 * PI * xf);
+    const double arg = ((double)x - (double)(T / 2)) * fc / (double)F;
+    const double sc = arg == 0.0 ? 1.0 : std::sin(PI * arg) / (PI * arg);
+    y[(size_t)x] = bh * bh * sc;
+    sum += y[(size_t)x];
+  }
+  sum /= (double)F;
+  for (int p = 0; p < F; ++p)
+    for (int n = 0; n < L; ++n) sincs[(size_t)(F - 1 - p) * L + n] = (float)(y[(size_t)(F * n + p)] / sum);   // sub-filter s = later fractional position
+}
+// how many output samples ohw_dsp_resample_sinc produces for n input samples: the chunk loop below without its dot products
+// (output k reads the input around position -L/2 + (k + 1) / ratio whatever chunk emits it)
+int64_t sinc_plan(int64_t n, double ratio) {
+  constexpr int L = 256, CHUNK = 1024;
+  const double t_ratio = 1.0 / ratio;
+  const double end_idx = (double)(CHUNK - (L + 1) - (int64_t)std::ceil(t_ratio));
+  double idx = -(double)(L / 2);
+  int64_t total = 0;
+  for (int64_t pos = 0; pos < n; pos += CHUNK) {
+    const int64_t len = n - pos < CHUNK ? n - pos : CHUNK;
+    int64_t made = 0;
+    while (idx < end_idx) { idx += t_ratio; ++made; }
+    idx -= (double)CHUNK;
+    if (len < CHUNK) {
+      const int64_t expected = (int64_t)std::ceil((double)len * ratio);
+      if (expected < made) made = expected;
+    }
+    total += made;
+  }
+  return total;
+}
+}  // namespace ohw
+
+extern "C" {
+
 namespace {
 struct SincResampler {
   static constexpr int L = 256, F = 256, CHUNK = 1024;
   double ratio, t_ratio, last_index;
   std::vector<float> sincs;     // [F][L]
   std::vector<float> buf;       // [2 L + CHUNK]
-  explicit SincResampler(double r) : ratio(r), t_ratio(1.0 / r), last_index(-(double)(L / 2)), sincs((size_t)F * L), buf((size_t)2 * L + CHUNK, 0.0f) {
-    const double fc = r >= 1.0 ? 0.95 : 0.95 * r;
-    const int T = L * F;
-    std::vector<double> y((size_t)T);
-    double sum = 0.0;
-    const double PI = 3.14159265358979323846;
-    for (int x = 0; x < T; ++x) {
-      const double xf = (double)x / (double)T;
-      const double bh = 0.35875 - 0.48829 * std::cos(2.0 * PI * xf) + 0.14128 * std::cos(4.0 * PI * xf) - 0.01168 * std::cos(6.0 * PI * xf);
-      const double arg = ((double)x - (double)(T / 2)) * fc / (double)F;
-      const double sc = arg == 0.0 ? 1.0 : std::sin(PI * arg) / (PI * arg);
-      y[(size_t)x] = bh * bh * sc;
-      sum += y[(size_t)x];
-    }
-    sum /= (double)F;
-    for (int p = 0; p < F; ++p)
-      for (int n = 0; n < L; ++n) sincs[(size_t)(F - 1 - p) * L + n] = (float)(y[(size_t)(F * n + p)] / sum);   // sub-filter s = later fractional position
+  explicit SincResampler(double r) : ratio(r), t_ratio(1.0 / r), last_index(-(double)(L / 2)), buf((size_t)2 * L + CHUNK, 0.0f) {
+    ohw::sinc_table(r, sincs);
   }
   float dot(int64_t index, int sub) const {
     const float* w = &buf[(size_t)index];

@@ -122,7 +122,7 @@ EXPORTS = [
     "ohw_ctx_create_shell", "ohw_ctx_blob_size", "ohw_ctx_blob_export", "ohw_ctx_blob_import",
     "ohw_default_preprocess_config", "ohw_preprocess_audio", "ohw_dsp_rms_db", "ohw_dsp_apply_gain", "ohw_dsp_normalize_rms",
     "ohw_dsp_compress", "ohw_dsp_limit", "ohw_dsp_resample_linear",
-    "ohw_greedy_ex", "ohw_state_set_logit_bias", "ohw_state_set_batch_invariant", "ohw_dbg_sample",
+    "ohw_resampler_create", "ohw_resampler_free", "ohw_resampler_out_len", "ohw_resampler_run", "ohw_greedy_ex", "ohw_state_set_logit_bias", "ohw_state_set_batch_invariant", "ohw_dbg_sample",
     "ohw_decode_active", "ohw_rng_new", "ohw_rng_free", "ohw_sample_host", "ohw_default_decode_policy", "ohw_engine_set_decode_policy",
     "ohw_engine_last_trace", "ohw_engine_set_schedule", "ohw_ctx_dtype",
     "ohw_beam_search", "ohw_encode_slice", "ohw_dsp_resample_sinc", "ohw_default_vad_config", "ohw_vad_state_new", "ohw_vad_state_free", "ohw_vad_state_update",
@@ -207,6 +207,12 @@ def lib():
         L.ohw_dsp_resample_linear.restype = C.c_int64
         L.ohw_dsp_resample_sinc.argtypes = [fp, C.c_int64, C.c_uint32, C.c_uint32, fp, C.c_int64]
         L.ohw_dsp_resample_sinc.restype = C.c_int64
+        L.ohw_resampler_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+        L.ohw_resampler_free.argtypes = [vp]
+        L.ohw_resampler_free.restype = None
+        L.ohw_resampler_out_len.argtypes = [vp, C.c_int64]
+        L.ohw_resampler_out_len.restype = C.c_int64
+        L.ohw_resampler_run.argtypes = [vp, vp, C.c_int64, C.c_int, vp, C.c_int64, C.c_int, vp]
         L.ohw_default_vad_config.argtypes = [C.POINTER(VadConfig)]
         L.ohw_default_vad_config.restype = None
         L.ohw_vad_state_new.argtypes = [C.POINTER(VadConfig), C.c_uint32]
@@ -761,6 +767,41 @@ def resample_sinc(samples: np.ndarray, from_rate: int, to_rate: int) -> np.ndarr
     if n:
         lib().ohw_dsp_resample_sinc(_fp(x), x.size, from_rate, to_rate, _fp(out), n)
     return out
+
+
+class DeviceResampler:
+    """ohw_resampler_*: the sinc resampler on the device (same output as resample_sinc up to fp32 summation order)"""
+    def __init__(self, from_rate: int, to_rate: int, device: int = 0):
+        self.h = C.c_void_p()
+        _check(lib().ohw_resampler_create(device, from_rate, to_rate, C.byref(self.h)))
+
+    def out_len(self, n: int) -> int:
+        return int(lib().ohw_resampler_out_len(self.h, n))
+
+    def run(self, samples: np.ndarray) -> np.ndarray:
+        """host samples in, host samples out"""
+        x = np.ascontiguousarray(samples, dtype=np.float32)
+        out = np.empty(self.out_len(x.size), np.float32)
+        if out.size:
+            _check(lib().ohw_resampler_run(self.h, x.ctypes.data_as(C.c_void_p), x.size, 0, out.ctypes.data_as(C.c_void_p), out.size, 0, None))
+        return out
+
+    def run_device(self, in_ptr: int, n: int, out_ptr: int, out_cap: int, stream: int = 0) -> int:
+        """device pointers (e.g. torch tensors' data_ptr()); asynchronous on `stream`; returns the number of output samples"""
+        m = self.out_len(n)
+        _check(lib().ohw_resampler_run(self.h, C.c_void_p(in_ptr), n, 1, C.c_void_p(out_ptr), out_cap, 1, C.c_void_p(stream) if stream else None))
+        return m
+
+    def close(self):
+        if self.h:
+            lib().ohw_resampler_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass
 
 
 def default_vad_config() -> VadConfig:
