@@ -121,6 +121,7 @@ struct ohw_state {
   bool batch_invariant = false;      // cross-attention variant picked from n_new alone (state_set_batch_invariant)
   std::vector<StepGraph> step_graphs;
   bool graphs_enabled = true;
+  int graph_max_batch = 32;         // graphs for batches below this (OHW_GRAPH_MAX_BATCH)
   // timing
   hipEvent_t ev[6]{};
   ohw_timings last{};
@@ -190,6 +191,12 @@ void state_alloc(ohw_state* st) {
   // already hides under the weights' first-byte latency); never with a split-K knob (the split path
   // publishes no statistics); dt must be a multiple of 32
   st->graphs_enabled = env_int("OHW_GRAPHS", 1, 0, 1) != 0;      // 0: the decode iterations are launched kernel by kernel (diagnostics)
+  // the greedy iteration is replayed as a hipGraph below this batch size only: a graph pays while the step is launch-bound
+  // (one window: 260 launches of 3 - 6 us); from 32 windows on a step's kernels outlast their launches (measured equal,
+  // 371.0 ms per 32-window batch either way) and in the LANES schedule the replayed graphs lose 2.4 % to sporadic 40-us
+  // stalls inside a replay (tools/lane_gap_analysis.py) - and a lane's first call no longer waits, at its capture, for the
+  // other lanes to leave the library
+  st->graph_max_batch = env_int("OHW_GRAPH_MAX_BATCH", 32, 1, 1 << 20);
   st->postnorm = env_int("OHW_DEC_POSTNORM", 0, 0, 1) != 0 && dec_ksplit_long() == 1 && dec_ksplit_short() == 1 && dt % 32 == 0;
   st->dx16.alloc(m_tiles * dt * 2, true);
   st->xstat.alloc((size_t)st->m_max * (dt / 16) * 2 * 4, true);
@@ -814,7 +821,7 @@ int ohw_greedy_ex(ohw_state* st, const ohw_sample_params* sp, int batch, int max
       // One greedy iteration = {feed next_tok, decoder step, sampler}.  It is launch-bound (about 260
       // short kernels), so it is captured once into a hipGraph and replayed; positions, tokens and
       // the done flags live in device memory, so the same graph serves every iteration.
-      const bool use_graph = st->graphs_enabled && st->prof_class == 0 && s != nullptr;
+      const bool use_graph = st->graphs_enabled && st->prof_class == 0 && s != nullptr && batch < st->graph_max_batch;
       hipGraphExec_t step_exec = nullptr;
       if (use_graph) {
         for (auto& g : st->step_graphs)

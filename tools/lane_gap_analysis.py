@@ -35,6 +35,7 @@ def main():
     for q, s, e, n in rows:
         byq[q].append((s, e, n))
     print(f"{len(rows)} dispatches on {len(byq)} queues")
+    t_first = min(r[1] for r in rows)
     for q, lst in sorted(byq.items(), key=lambda kv: -len(kv[1])):
         lst.sort()
         dec = [x for x in lst if x[2].startswith(("cross_attn", "self_attn", "dec_gemm", "sampler", "embed"))]
@@ -43,6 +44,7 @@ def main():
             continue
         # decode segments: consecutive decoder dispatches with no other kernel of this queue in between and gaps < 1 ms
         kt = 0
+        segs, long_gaps = [], []
         gaps = defaultdict(list)
         seg_wall = 0
         seg_start = dec[0][0]
@@ -54,6 +56,8 @@ def main():
             g = cur[0] - prev[1]
             if g > 1_000_000:                      # another group's front ends ran in between
                 seg_wall += prev[1] - seg_start
+                segs.append((seg_start, prev[1]))
+                long_gaps.append(g)
                 seg_start = cur[0]
             else:
                 gaps[(prev[2], cur[2])].append(g)
@@ -61,6 +65,13 @@ def main():
             kern[cur[2]].append(cur[1] - cur[0])
             prev = cur
         seg_wall += prev[1] - seg_start
+        segs.append((seg_start, prev[1]))
+        print(f"queue {q}: decode segments (ms, relative to the first dispatch of the trace): " +
+              ", ".join(f"{(a - t_first) / 1e6:.1f}..{(b - t_first) / 1e6:.1f}" for a, b in segs) +
+              f"; gaps over 1 ms between them: {[round(g / 1e6, 1) for g in long_gaps]}")
+        # gaps of 20 us .. 1 ms inside a segment: host round trips (the greedy loop reads n_done every few iterations)
+        mid = [g for v in gaps.values() for g in v if g > 20_000]
+        print(f"   gaps of 20 us .. 1 ms inside the segments: {len(mid)}, {sum(mid) / 1e6:.1f} ms in total")
         allg = [g for v in gaps.values() for g in v]
         print(f"queue {q}: {len(dec)} decoder dispatches, decode wall {seg_wall / 1e6:.1f} ms = kernels {kt / 1e6:.1f} ms ({100 * kt / seg_wall:.0f} %) + gaps "
               f"{sum(allg) / 1e6:.1f} ms ({100 * sum(allg) / seg_wall:.0f} %); mean gap {sum(allg) / max(1, len(allg)) / 1e3:.2f} us, median "
