@@ -53,12 +53,13 @@ def main():
                     help="with --pipeline: decodes in flight beside the front end (each on its own CU-masked stream, driven by its own "
                          "host thread): the latency-bound GEMM chain of one decode hides under the K/V stream of the other")
     ap.add_argument("--phases", type=int, default=4,
-                    help="G > 1 (default 4, the engine's LANES schedule): the front ends of G x --merge batches run one after the other on "
+                    help="G > 1 (default 4, the engine's LANES schedule): the front ends of G lanes (--merge batches each) run one after the other on "
                          "every CU, then G decodes side by side on G disjoint CU sets (one's latency-bound GEMM chain under the others' K/V "
                          "streams); 0 or 1: see --pipeline")
-    ap.add_argument("--merge", type=int, default=2,
-                    help="with --phases: batches decoded TOGETHER by one lane (ohw_encode_slice: their front ends feed one decode batch of "
-                         "merge x batch rows - the decoder streams its weights once per step whatever its batch)")
+    ap.add_argument("--merge", type=int, default=3,
+                    help="with --phases: batches (steps) one lane takes through ONE front-end pass and ONE decode of merge x batch "
+                         "windows - the decoder streams its weights once per token whatever its batch, and 96 windows fill the "
+                         "encoder GEMMs' last round of 256-row tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=0, help="decode tokens in the CPU sample (0 = same as --tokens)")
     ap.add_argument("--cpu-windows", type=int, default=2, help="30 s windows in the CPU sample")
@@ -178,6 +179,7 @@ def main():
             dss = [E.Stream(local_rank, l * (n_cu // G), n_cu // G) for l in range(G)]
             es = ds = full
             pst = [E.State(ctx, B * MG) for _ in range(G)]
+            pcm_rep = pcm.repeat(MG, 1) if MG > 1 else pcm       # a lane's windows: MG steps of the same B synthetic windows
             pipe = {"schedule": "lanes", "decoders_side_by_side": G, "batches_per_decode": MG, "decoder_cus": n_cu // G,
                     "batches_in_flight": G * MG}
         except E.WhisperError as ex:
@@ -201,9 +203,11 @@ def main():
                 for j, steps_j in enumerate(lanes):
                     s_ = pst[j]
                     s_.set_stream(full.ptr)
-                    for k in range(len(steps_j)):
-                        s_.mel_device(pcm.data_ptr(), pcm.shape[1], n_samples, E.OHW_MEL_ZERO_TAIL)
-                        s_.encode_slice(B, k * B, len(steps_j) * B)
+                    # ONE front-end pass over the lane's len(steps_j) x B windows (the engine does the same): 96 windows fill
+                    # the last round of the encoder GEMMs' 256-row tiles where 32 leave it two thirds empty
+                    c = len(steps_j)
+                    s_.mel_device(pcm_rep.data_ptr(), pcm_rep.shape[1], n_samples * c, E.OHW_MEL_ZERO_TAIL)
+                    s_.encode(c * B)
                 # the host waits for the group's front ends before it starts the lane threads: lanes that begin to enqueue
                 # their decode while the front ends still run cost 6 % of a step (283.9 against 261.7 - 268.2 ms, measured)
                 dbg = os.environ.get("OHW_BENCH_DEBUG") == "1"
@@ -338,7 +342,7 @@ def main():
     if pipe and G > 1:
         # set-up, not a step: the decode graphs are captured per (state, decode-batch size) on first use and a capture holds
         # the library's gate against every other lane, so each lane meets every group shape the K timed steps will use before
-        # the warm-up (K = 20 on 4 lanes x 2: groups of 8, 8 and 4)
+        # the warm-up (K = 20 on 4 lanes x 3: a group of 12 and one of 8)
         for shape in sorted({min(G * MG, args.steps - g0) for g0 in range(0, args.steps, G * MG)}, reverse=True):
             run_steps(shape)
     toks = run_steps(args.warmup)

@@ -514,10 +514,10 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
         }
         restore();
       } else {
-        // LANES: groups of L decode batches, each of up to `merge` front-end batches.  The front ends (max_batch windows each)
-        // run one after the other on every CU (MFMA-bound: nothing to gain from sharing the chip) and write their cross K/V
-        // into their lane's decode batch (ohw_encode_slice: the decoder streams its weights once per step whatever its
-        // batch); then the L decodes run side by side, each on its own CU-masked stream driven by its own host thread - a
+        // LANES: groups of up to L lanes, each lane up to `merge` batches of max_batch windows.  The lanes' front ends (one
+        // pass over all of a lane's windows each) run one after the other on every CU (MFMA-bound: nothing to gain from
+        // sharing the chip); a lane decodes its windows as ONE batch (the decoder streams its weights once per step whatever
+        // its batch); the L decodes run side by side, each on its own CU-masked stream driven by its own host thread - a
         // decode alternates an HBM-bound kernel (cross-attention) with a chain of latency-bound ones, and several together
         // keep HBM busy (tools/decode_overlap_probe.py).  The kernels' arithmetic does not depend on the CU budget or on a
         // window's batch neighbours, so the results equal the sequential schedule's.
@@ -548,12 +548,11 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
               const int Wd = lane_w[(size_t)j];
               ohw_state* st = e->lane_states[(size_t)j];
               check(ohw_state_set_stream(st, e->s_full));
-              for (int f = 0; f < Wd; f += e->max_batch) {
-                const int Bf = std::min(e->max_batch, Wd - f);
-                for (int b = 0; b < Bf; ++b) nss[(size_t)j][(size_t)(f + b)] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + f + b) * CHUNK_SAMPLES);
-                mel_windows(st, w0 + f, Bf, &nss[(size_t)j][(size_t)f]);
-                check(ohw_encode_slice(st, Bf, f, Wd));
-              }
+              // ONE front-end pass over all the lane's windows (its state holds them): the encoder's GEMMs run in rounds of
+              // 256 tiles of 256 rows, and 96 windows (563 row tiles) fill their last round where 32 (188) leave it 2/3 empty
+              for (int b = 0; b < Wd; ++b) nss[(size_t)j][(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + b) * CHUNK_SAMPLES);
+              mel_windows(st, w0, Wd, nss[(size_t)j].data());
+              check(ohw_encode(st, Wd));
             }
             if (grp == 1) {
               decode_windows(*scs[0], e->lane_states[0], lane_w0[0], lane_w[0], nss[0].data());

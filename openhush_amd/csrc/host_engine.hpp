@@ -25,7 +25,7 @@ struct ohw_engine {
   void* s_full = nullptr; void* s_enc = nullptr; void* s_dec = nullptr;
   int schedule = OHW_SCHEDULE_LANES;     // how audio longer than max_batch windows is overlapped (include/ohw.h)
   int lanes = 4;                         // decodes side by side in the LANES schedule
-  int merge = 2;                         // front-end batches decoded together by one lane (ohw_encode_slice)
+  int merge = 3;                         // batches of max_batch windows a lane takes through ONE front-end pass and ONE decode
   int enc_cus = 96;
   int device = 0;
   ohw_decode_policy policy{0.2f, 2.4f, -1.0f, 0.6f};
