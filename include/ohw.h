@@ -387,13 +387,14 @@ int ohw_engine_set_window_mode(ohw_engine* e, int mode);
  *   SEQUENTIAL  one batch after the other;
  *   PIPELINE    front end (mel, encoder, cross K/V) of batch i+1 on OHW_ENGINE_ENC_CUS compute units beside the decode of
  *               batch i on the rest (round 1's schedule);
- *   LANES       (default) groups of `lanes` decode batches, each fed by up to `merge` front-end batches of max_batch windows
- *               (ohw_encode_slice): the front ends run one after the other on every compute unit, then the decodes side
- *               by side, each on its own CU-masked stream and host thread - a decode alternates an HBM-bound kernel with a
- *               latency-bound chain, several of them together keep HBM busy, and a merged decode streams the weights once
- *               for all its windows.
- * The schedule's extra states and streams are made when a long input first needs them; environment defaults:
- * OHW_ENGINE_SCHEDULE = sequential | pipeline | lanes, OHW_ENGINE_LANES (2), OHW_ENGINE_MERGE (4), OHW_ENGINE_ENC_CUS (96). */
+ *   LANES       (default) groups of up to `lanes` lanes, each of up to `merge` batches of max_batch windows (dealt evenly):
+ *               a lane takes its windows through ONE front-end pass and decodes them as ONE batch; the lanes' front ends run
+ *               one after the other on every compute unit, then their decodes side by side, each on its own CU-masked
+ *               stream and host thread - a decode alternates an HBM-bound kernel with a latency-bound chain, several of
+ *               them together keep HBM busy, and a larger decode batch streams the decoder's weights once for all its rows.
+ * The schedule's extra states and streams are made when a long input first needs them (a lane's state holds up to
+ * merge x max_batch windows: 245.76 MB of cross K/V per window at large-v3); environment defaults:
+ * OHW_ENGINE_SCHEDULE = sequential | pipeline | lanes, OHW_ENGINE_LANES (4), OHW_ENGINE_MERGE (3), OHW_ENGINE_ENC_CUS (96). */
 enum { OHW_SCHEDULE_SEQUENTIAL = 0, OHW_SCHEDULE_PIPELINE = 1, OHW_SCHEDULE_LANES = 2 };
 int ohw_engine_set_schedule(ohw_engine* e, int schedule, int lanes /* 0 = keep */, int merge /* 0 = keep */);
 /* tokens of the last transcribe, per 30 s window concatenated (for parity tests)                  */
