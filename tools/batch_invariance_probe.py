@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--preset", default="large-v3")
     ap.add_argument("--small", type=int, default=32)
     ap.add_argument("--big", type=int, default=120)
+    ap.add_argument("--cus", type=int, default=0, help="run the big state on a CU-masked stream of this many compute units (a LANES lane: 64)")
     ap.add_argument("--invariant", type=int, default=1, help="ohw_state_set_batch_invariant on both states")
     a = ap.parse_args()
     hp = synth.PRESETS[a.preset]
@@ -26,6 +27,10 @@ def main():
     prompt = np.asarray([tok.sot, tok.sot + 1, tok.transcribe, tok.no_timestamps], np.int32)
     sa, sb = E.State(ctx, a.small), E.State(ctx, a.big)
     sa.set_batch_invariant(bool(a.invariant)); sb.set_batch_invariant(bool(a.invariant))
+    lane = None
+    if a.cus > 0:
+        lane = E.Stream(0, 0, a.cus)
+        sb.set_stream(lane.ptr)
     for f in range(0, a.big, a.small):
         n = min(a.small, a.big - f)
         sb.mel(pcm[f:f + n], None, E.OHW_MEL_ZERO_TAIL, want=False); sb.encode_slice(n, f, a.big)
