@@ -171,6 +171,43 @@ void ohw_vad_energy_engine_free(ohw_vad_engine* e);
 int64_t ohw_vad_run(const ohw_vad_engine* engine, const ohw_vad_config* cfg, const float* samples, int64_t n, int64_t poll_samples,
                     ohw_speech_segment* out, int64_t cap);
 
+/* ---- streaming glue right after the path, host code -----------------------------------------------
+ *      ohw_tracker_*: TranscriptionTracker (reference src/queue/mod.rs:59-297) - chunks are registered as pending under
+ *      back-pressure, results come back in any order, take_ready releases them (streaming mode: all completed chunks sorted
+ *      by (sequence, chunk), the words that repeat the end of the previous output removed; ordered mode: recordings in
+ *      sequence order).  ohw_extract_chunk: AudioRecorder::extract_chunk for a 16 kHz recorder (src/input/audio.rs:737-785:
+ *      nothing below 0.1 s, zero padding to 1.1 s).  ohw_chunk_scheduler_*: the chunk-timer arm of the daemon loop
+ *      (src/daemon.rs:1958-2011).  Strings are UTF-8; a text returned by ohw_tracker_ready_get lives until the next
+ *      take_ready on that tracker. */
+enum { OHW_BACKPRESSURE_WARN = 0, OHW_BACKPRESSURE_DROP_OLDEST = 1, OHW_BACKPRESSURE_DROP_NEWEST = 2 };
+typedef struct ohw_tracker ohw_tracker;
+ohw_tracker* ohw_tracker_new(int streaming);
+void ohw_tracker_free(ohw_tracker* t);
+/* 1 = accepted, 0 = refused (DROP_NEWEST at max_pending), negative = error; max_pending 0 = unlimited */
+int ohw_tracker_add_pending(ohw_tracker* t, uint64_t sequence_id, uint32_t chunk_id, uint32_t max_pending, uint32_t high_water_mark, int strategy);
+int ohw_tracker_add_result(ohw_tracker* t, const char* text, uint64_t sequence_id, uint32_t chunk_id, int is_final, float duration_secs);
+int ohw_tracker_take_ready(ohw_tracker* t);   /* number of released results, read with ohw_tracker_ready_get(t, 0 .. n-1, ..) */
+int ohw_tracker_ready_get(const ohw_tracker* t, int i, const char** text, uint64_t* sequence_id, uint32_t* chunk_id, int* is_final,
+                          float* duration_secs);
+void ohw_tracker_reset_dedup(ohw_tracker* t);
+int ohw_tracker_is_empty(const ohw_tracker* t);
+int ohw_tracker_is_pending(const ohw_tracker* t, uint64_t sequence_id, uint32_t chunk_id);
+int ohw_tracker_pending_count(const ohw_tracker* t);
+int ohw_tracker_waiting_count(const ohw_tracker* t);
+/* length of the chunk [from_pos, to_pos) after padding (0: shorter than 0.1 s); written to out when out_cap suffices */
+int64_t ohw_extract_chunk(const float* recording, int64_t n_recording, int64_t from_pos, int64_t to_pos, float* out, int64_t out_cap);
+typedef struct ohw_chunk_scheduler ohw_chunk_scheduler;
+ohw_chunk_scheduler* ohw_chunk_scheduler_new(ohw_tracker* tracker, uint64_t sequence_id, uint32_t max_pending, uint32_t high_water_mark,
+                                             int strategy);
+void ohw_chunk_scheduler_free(ohw_chunk_scheduler* s);
+/* one timer tick at recorder position current_pos: the job's length (its samples: ohw_extract_chunk(*from_pos, current_pos)) and
+ * id, or 0 - too short (nothing moved) or refused by the tracker (position and id moved on, as in the reference) */
+int64_t ohw_chunk_scheduler_tick(ohw_chunk_scheduler* s, const float* recording, int64_t n_recording, int64_t current_pos,
+                                 uint32_t* chunk_id, int64_t* from_pos);
+int64_t ohw_chunk_scheduler_position(const ohw_chunk_scheduler* s);
+uint32_t ohw_chunk_scheduler_next_id(const ohw_chunk_scheduler* s);
+int64_t ohw_chunk_scheduler_rejected(const ohw_chunk_scheduler* s);
+
 /* ---- state: replaces ctx.create_state() (reference src/engine/whisper.rs:167-169) ------------- */
 /* max_batch = number of independent 30 s windows processed together (the reference: 1)           */
 int ohw_state_create(ohw_ctx* ctx, int max_batch, ohw_state** out);

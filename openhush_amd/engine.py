@@ -122,7 +122,10 @@ EXPORTS = [
     "ohw_ctx_create_shell", "ohw_ctx_blob_size", "ohw_ctx_blob_export", "ohw_ctx_blob_import",
     "ohw_default_preprocess_config", "ohw_preprocess_audio", "ohw_dsp_rms_db", "ohw_dsp_apply_gain", "ohw_dsp_normalize_rms",
     "ohw_dsp_compress", "ohw_dsp_limit", "ohw_dsp_resample_linear",
-    "ohw_resampler_create", "ohw_resampler_free", "ohw_resampler_out_len", "ohw_resampler_run", "ohw_greedy_ex", "ohw_state_set_logit_bias", "ohw_state_set_batch_invariant", "ohw_dbg_sample",
+    "ohw_tracker_new", "ohw_tracker_free", "ohw_tracker_add_pending", "ohw_tracker_add_result", "ohw_tracker_take_ready", "ohw_tracker_ready_get",
+    "ohw_tracker_reset_dedup", "ohw_tracker_is_empty", "ohw_tracker_is_pending", "ohw_tracker_pending_count", "ohw_tracker_waiting_count", "ohw_extract_chunk",
+    "ohw_chunk_scheduler_new", "ohw_chunk_scheduler_free", "ohw_chunk_scheduler_tick", "ohw_chunk_scheduler_position", "ohw_chunk_scheduler_next_id",
+    "ohw_chunk_scheduler_rejected", "ohw_resampler_create", "ohw_resampler_free", "ohw_resampler_out_len", "ohw_resampler_run", "ohw_greedy_ex", "ohw_state_set_logit_bias", "ohw_state_set_batch_invariant", "ohw_dbg_sample",
     "ohw_decode_active", "ohw_rng_new", "ohw_rng_free", "ohw_sample_host", "ohw_default_decode_policy", "ohw_engine_set_decode_policy",
     "ohw_engine_last_trace", "ohw_engine_set_schedule", "ohw_ctx_dtype",
     "ohw_beam_search", "ohw_encode_slice", "ohw_dsp_resample_sinc", "ohw_default_vad_config", "ohw_vad_state_new", "ohw_vad_state_free", "ohw_vad_state_update",
@@ -208,6 +211,34 @@ def lib():
         L.ohw_dsp_resample_sinc.argtypes = [fp, C.c_int64, C.c_uint32, C.c_uint32, fp, C.c_int64]
         L.ohw_dsp_resample_sinc.restype = C.c_int64
         L.ohw_resampler_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+        L.ohw_tracker_new.argtypes = [C.c_int]
+        L.ohw_tracker_new.restype = vp
+        L.ohw_tracker_free.argtypes = [vp]
+        L.ohw_tracker_free.restype = None
+        L.ohw_tracker_add_pending.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.ohw_tracker_add_result.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_float]
+        L.ohw_tracker_take_ready.argtypes = [vp]
+        L.ohw_tracker_ready_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int),
+                                            C.POINTER(C.c_float)]
+        L.ohw_tracker_reset_dedup.argtypes = [vp]
+        L.ohw_tracker_reset_dedup.restype = None
+        for fn in (L.ohw_tracker_is_empty, L.ohw_tracker_pending_count, L.ohw_tracker_waiting_count):
+            fn.argtypes = [vp]
+        L.ohw_tracker_is_pending.argtypes = [vp, C.c_uint64, C.c_uint32]
+        L.ohw_extract_chunk.argtypes = [fp, C.c_int64, C.c_int64, C.c_int64, fp, C.c_int64]
+        L.ohw_extract_chunk.restype = C.c_int64
+        L.ohw_chunk_scheduler_new.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
+        L.ohw_chunk_scheduler_new.restype = vp
+        L.ohw_chunk_scheduler_free.argtypes = [vp]
+        L.ohw_chunk_scheduler_free.restype = None
+        L.ohw_chunk_scheduler_tick.argtypes = [vp, fp, C.c_int64, C.c_int64, C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
+        L.ohw_chunk_scheduler_tick.restype = C.c_int64
+        L.ohw_chunk_scheduler_position.argtypes = [vp]
+        L.ohw_chunk_scheduler_position.restype = C.c_int64
+        L.ohw_chunk_scheduler_next_id.argtypes = [vp]
+        L.ohw_chunk_scheduler_next_id.restype = C.c_uint32
+        L.ohw_chunk_scheduler_rejected.argtypes = [vp]
+        L.ohw_chunk_scheduler_rejected.restype = C.c_int64
         L.ohw_resampler_free.argtypes = [vp]
         L.ohw_resampler_free.restype = None
         L.ohw_resampler_out_len.argtypes = [vp, C.c_int64]

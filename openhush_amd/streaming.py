@@ -71,6 +71,62 @@ class ChunkScheduler:
         return job
 
 
+class NativeChunkScheduler:
+    """The scheduler behind the C ABI (ohw_chunk_scheduler_*, csrc/tracker.cpp) on a NativeTranscriptionTracker; same
+    interface and behaviour as ChunkScheduler."""
+    def __init__(self, tracker, sequence_id: int, max_pending: int = 10, high_water_mark: int = 8,
+                 strategy: BackpressureStrategy = BackpressureStrategy.WARN):
+        import ctypes as C
+        from .tracker import _STRATEGY_CODE
+        self._C, self._L = C, E.lib()
+        self.tracker, self.sequence_id = tracker, sequence_id
+        self.h = C.c_void_p(self._L.ohw_chunk_scheduler_new(tracker.h, sequence_id, max_pending, high_water_mark, _STRATEGY_CODE[strategy]))
+        if not self.h:
+            raise ValueError("ohw_chunk_scheduler_new")
+
+    last_chunk_pos = property(lambda self: int(self._L.ohw_chunk_scheduler_position(self.h)))
+    next_chunk_id = property(lambda self: int(self._L.ohw_chunk_scheduler_next_id(self.h)))
+    rejected = property(lambda self: int(self._L.ohw_chunk_scheduler_rejected(self.h)))
+
+    def tick(self, recording: np.ndarray, current_pos: int, is_final: bool = False) -> Optional[ChunkJob]:
+        C = self._C
+        rec = np.ascontiguousarray(recording, dtype=np.float32)
+        fp = C.POINTER(C.c_float)
+        cid, frm = C.c_uint32(), C.c_int64()
+        n = int(self._L.ohw_chunk_scheduler_tick(self.h, rec.ctypes.data_as(fp), rec.size, current_pos, C.byref(cid), C.byref(frm)))
+        if n < 0:
+            raise ValueError("ohw_chunk_scheduler_tick")
+        if n == 0:
+            return None
+        buf = np.empty(n, np.float32)
+        self._L.ohw_extract_chunk(rec.ctypes.data_as(fp), rec.size, frm.value, current_pos, buf.ctypes.data_as(fp), n)
+        return ChunkJob(buf, self.sequence_id, int(cid.value), is_final)
+
+    def close(self):
+        if self.h:
+            self._L.ohw_chunk_scheduler_free(self.h)
+            self.h = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+def native_extract_chunk(recording: np.ndarray, from_pos: int, to_pos: int) -> Optional[np.ndarray]:
+    """ohw_extract_chunk"""
+    import ctypes as C
+    rec = np.ascontiguousarray(recording, dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    n = int(E.lib().ohw_extract_chunk(rec.ctypes.data_as(fp), rec.size, from_pos, to_pos, C.cast(None, fp), 0))
+    if n <= 0:
+        return None
+    out = np.empty(n, np.float32)
+    E.lib().ohw_extract_chunk(rec.ctypes.data_as(fp), rec.size, from_pos, to_pos, out.ctypes.data_as(fp), n)
+    return out
+
+
 class StreamingSession:
     """Chunks of one recording through the MI355X path.  beam_size 0 = greedy; vad: callable samples -> probability (the
     VadEngine hook) with `vad_threshold`, or None."""

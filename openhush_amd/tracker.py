@@ -115,3 +115,84 @@ class TranscriptionTracker:
 
     def waiting_count(self) -> int:
         return len(self.completed)
+
+
+_STRATEGY_CODE = {BackpressureStrategy.WARN: 0, BackpressureStrategy.DROP_OLDEST: 1, BackpressureStrategy.DROP_NEWEST: 2}
+
+
+class NativeTranscriptionTracker:
+    """The same tracker behind the C ABI (ohw_tracker_*, openhush_amd/csrc/tracker.cpp): what a C or Rust host links.  Same
+    methods and results as TranscriptionTracker above; tests/test_tracker.py runs the reference's cases through both."""
+    def __init__(self, streaming: bool = True):
+        import ctypes as C
+        from . import engine as E
+        self._C, self._L = C, E.lib()
+        self.h = C.c_void_p(self._L.ohw_tracker_new(int(streaming)))
+        if not self.h:
+            raise MemoryError("ohw_tracker_new")
+
+    @classmethod
+    def new_ordered(cls) -> "NativeTranscriptionTracker":
+        return cls(streaming=False)
+
+    def add_pending(self, sequence_id: int, chunk_id: int) -> bool:
+        return self.add_pending_with_config(sequence_id, chunk_id, 10, 8, BackpressureStrategy.WARN)
+
+    def add_pending_with_config(self, sequence_id: int, chunk_id: int, max_pending: int, high_water_mark: int,
+                                strategy: BackpressureStrategy) -> bool:
+        rc = self._L.ohw_tracker_add_pending(self.h, sequence_id, chunk_id, max_pending, high_water_mark, _STRATEGY_CODE[strategy])
+        if rc < 0:
+            raise ValueError("ohw_tracker_add_pending")
+        return rc == 1
+
+    def add_result(self, result: ChunkResult):
+        self._L.ohw_tracker_add_result(self.h, result.text.encode("utf-8"), result.sequence_id, result.chunk_id, int(result.is_final),
+                                       float(result.duration_secs))
+
+    def take_ready(self) -> List[ChunkResult]:
+        C = self._C
+        n = self._L.ohw_tracker_take_ready(self.h)
+        out = []
+        for i in range(n):
+            text, seq, chunk, fin, dur = C.c_char_p(), C.c_uint64(), C.c_uint32(), C.c_int(), C.c_float()
+            self._L.ohw_tracker_ready_get(self.h, i, C.byref(text), C.byref(seq), C.byref(chunk), C.byref(fin), C.byref(dur))
+            out.append(ChunkResult(text.value.decode("utf-8"), int(seq.value), int(chunk.value), bool(fin.value), float(dur.value)))
+        return out
+
+    class _Pending:
+        def __init__(self, owner):
+            self.o = owner
+
+        def __contains__(self, key) -> bool:
+            return bool(self.o._L.ohw_tracker_is_pending(self.o.h, key[0], key[1]))
+
+    @property
+    def pending(self):
+        """supports `(sequence_id, chunk_id) in tracker.pending`"""
+        return NativeTranscriptionTracker._Pending(self)
+
+    def reset_dedup(self):
+        self._L.ohw_tracker_reset_dedup(self.h)
+
+    def is_empty(self) -> bool:
+        return bool(self._L.ohw_tracker_is_empty(self.h))
+
+    def pending_count(self) -> int:
+        return int(self._L.ohw_tracker_pending_count(self.h))
+
+    def waiting_count(self) -> int:
+        return int(self._L.ohw_tracker_waiting_count(self.h))
+
+    def stats(self) -> QueueStats:
+        return QueueStats(self.pending_count(), self.waiting_count())
+
+    def close(self):
+        if self.h:
+            self._L.ohw_tracker_free(self.h)
+            self.h = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass

@@ -9,23 +9,34 @@ from openhush_amd import synth
 from openhush_amd.tracker import BackpressureStrategy, ChunkResult, TranscriptionTracker
 
 
-def test_extract_chunk_lengths():
+@pytest.fixture(params=["python", "native"])
+def impl(request):
+    """(extract_chunk, tracker class, scheduler class): the Python mirror and the C++ code behind the C ABI (csrc/tracker.cpp)"""
+    from openhush_amd.tracker import NativeTranscriptionTracker
+    if request.param == "python":
+        return S.extract_chunk, TranscriptionTracker, S.ChunkScheduler
+    return S.native_extract_chunk, NativeTranscriptionTracker, S.NativeChunkScheduler
+
+
+def test_extract_chunk_lengths(impl):
+    extract_chunk = impl[0]
     rec = np.arange(16000 * 8, dtype=np.float32)
-    assert S.extract_chunk(rec, 0, 0) is None                              # empty
-    assert S.extract_chunk(rec, 100, 100 + 1599) is None                   # 0.0999 s < 0.1 s
-    c = S.extract_chunk(rec, 100, 100 + 1600)                              # exactly 0.1 s: kept, padded to 1.1 s
+    assert extract_chunk(rec, 0, 0) is None                              # empty
+    assert extract_chunk(rec, 100, 100 + 1599) is None                     # 0.0999 s < 0.1 s
+    c = extract_chunk(rec, 100, 100 + 1600)                              # exactly 0.1 s: kept, padded to 1.1 s
     assert c.size == 17600 and np.array_equal(c[:1600], rec[100:1700]) and not c[1600:].any()
-    c = S.extract_chunk(rec, 0, 17599)                                     # 1.0999 s: padded by one sample
+    c = extract_chunk(rec, 0, 17599)                                     # 1.0999 s: padded by one sample
     assert c.size == 17600 and c[-1] == 0.0
-    c = S.extract_chunk(rec, 0, 17600)
+    c = extract_chunk(rec, 0, 17600)
     assert c.size == 17600 and c[-1] == rec[17599]
-    c = S.extract_chunk(rec, 16000, 16000 * 6)                             # 5 s: as it is
+    c = extract_chunk(rec, 16000, 16000 * 6)                             # 5 s: as it is
     assert c.size == 80000 and np.array_equal(c, rec[16000:96000])
 
 
-def test_scheduler_positions_and_ids():
-    tr = TranscriptionTracker()
-    sch = S.ChunkScheduler(tr, sequence_id=7)
+def test_scheduler_positions_and_ids(impl):
+    _, Tracker, Scheduler = impl
+    tr = Tracker()
+    sch = Scheduler(tr, sequence_id=7)
     rec = np.zeros(16000 * 20, np.float32)
     assert sch.tick(rec, 800) is None                                      # too short: neither the position nor the id moves
     assert (sch.last_chunk_pos, sch.next_chunk_id) == (0, 0)
@@ -37,9 +48,10 @@ def test_scheduler_positions_and_ids():
     assert tr.pending_count() == 2
 
 
-def test_scheduler_backpressure_drop_newest_still_advances():
-    tr = TranscriptionTracker()
-    sch = S.ChunkScheduler(tr, 1, max_pending=2, high_water_mark=1, strategy=BackpressureStrategy.DROP_NEWEST)
+def test_scheduler_backpressure_drop_newest_still_advances(impl):
+    _, Tracker, Scheduler = impl
+    tr = Tracker()
+    sch = Scheduler(tr, 1, max_pending=2, high_water_mark=1, strategy=BackpressureStrategy.DROP_NEWEST)
     rec = np.zeros(16000 * 30, np.float32)
     assert sch.tick(rec, 16000 * 5) is not None and sch.tick(rec, 16000 * 10) is not None
     assert sch.tick(rec, 16000 * 15) is None                               # refused: "skip submitting the job but still update state"
