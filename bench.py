@@ -172,6 +172,8 @@ def main():
     D = max(1, args.decoders)
     G = max(0, args.phases)
     MG = max(1, args.merge)
+    if rehearse:
+        MG = 1        # the ranks of a rehearsal share ONE GPU's memory: lanes of one batch (a 96-window lane holds 37 GB)
     if G > 1 and S == 1:
         n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
         try:
