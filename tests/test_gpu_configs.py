@@ -210,6 +210,38 @@ def test_config4_one_hour_120_windows_on_one_gpu(E, large_v3_file, monkeypatch):
     assert len(out["0"][0]) > 0
 
 
+def test_large_v3_window_result_does_not_depend_on_its_batch(E, large_v3_file):
+    """Size-independent property at BASELINE dimensions: 40 large-v3 windows decoded as one 40-row batch on a 64-CU stream (a
+    LANES lane: four n-tiles per workgroup in the decoder GEMMs) against the same windows as batches of 32 + 8 on the whole
+    chip - logits of the prompt pass and of a single-token step, greedy tokens and their log-probabilities, bit for bit
+    (ohw_state_set_batch_invariant; what makes every schedule of ohw_engine_transcribe give the same tokens)."""
+    ctx = E.Context.from_file(large_v3_file, 0, E.OHW_DTYPE_BF16)
+    n = 40
+    pcm = np.stack([synth.synth_audio(3000 + w) for w in range(n)])
+    tok = ctx.tok
+    prompt = np.asarray([tok.sot, tok.sot + 1, tok.transcribe, tok.no_timestamps], np.int32)
+    p = ctx.default_params(); p.force_len = 24
+    lane = E.Stream(0, 0, 64)
+    big = E.State(ctx, n)
+    big.set_batch_invariant(True)
+    big.set_stream(lane.ptr)
+    big.mel(pcm, None, E.OHW_MEL_ZERO_TAIL, want=False); big.encode(n)
+    L0 = big.decode(np.tile(prompt, (n, 1)), [0] * n)
+    L1 = big.decode(L0.argmax(axis=1).astype(np.int32)[:, None], [4] * n)
+    G = big.greedy_ex(n, p)
+    small = E.State(ctx, 32)
+    small.set_batch_invariant(True)
+    for f, m in ((0, 32), (32, 8)):
+        small.mel(pcm[f:f + m], None, E.OHW_MEL_ZERO_TAIL, want=False); small.encode(m)
+        l0 = small.decode(np.tile(prompt, (m, 1)), [0] * m)
+        l1 = small.decode(l0.argmax(axis=1).astype(np.int32)[:, None], [4] * m)
+        g = small.greedy_ex(m, p)
+        assert np.array_equal(l0, L0[f:f + m]) and np.array_equal(l1, L1[f:f + m]), f
+        for a, b in zip(g, G[f:f + m]):
+            assert a["tokens"] == b["tokens"] and np.array_equal(a["logprobs"], b["logprobs"]), f
+    big.close(); small.close(); lane.close()
+
+
 def _worker_large(rank, world, port, model_path, n_windows, q):
     import torch.distributed as dist
     from openhush_amd import engine as E, shard
