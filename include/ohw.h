@@ -221,7 +221,8 @@ const ohw_ctx* ohw_state_ctx(const ohw_state* st);
  *      transcribes one buffer at a time).  The encoder is MFMA-bound and the decoder HBM/latency-bound, so the engine
  *      runs the encoder of batch i+1 beside the decoder of batch i on DISJOINT sets of compute units: a stream made here
  *      is restricted to CU-mask bits [first_cu, first_cu + n_cu) (bits are dealt round-robin over the 8 XCDs, so any
- *      contiguous range is spread evenly); n_cu = 0 makes an unrestricted stream.  ohw_stream_wait makes `waiter` wait
+ *      contiguous range is spread evenly; a mask that would leave an XCD without any CU is not honoured by the
+ *      runtime - tools/probes/xcd_mask_probe.hip - so whole-XCD partitions cannot be made); n_cu = 0 makes an unrestricted stream.  ohw_stream_wait makes `waiter` wait
  *      for everything enqueued on `signal` so far (event record + wait, no host sync). ------------------------------- */
 int ohw_stream_create(int device, int first_cu, int n_cu, void** stream_out);
 int ohw_stream_destroy(void* stream);
