@@ -10,6 +10,8 @@
 //                 (cdna_hip_programming.md section 3 "An accumulator tile as the next MFMA's operand")
 //                 and V^T fragments come from row-major V via ds_read_b64_tr_b16.
 // d_head = 64 makes this softmax(VALU)-heavy: 256 flop per exp; the bound is MFMA/VALU co-issue, not HBM.
+#include <type_traits>
+
 #include "attention.hpp"
 
 namespace ohw {
@@ -60,25 +62,32 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void encoder_attention_kernel(const
     v_lds[i] = 8192 + r * 128 + ((schunk ^ v_swz(r)) << 4);
   }
   const int nkb = (t_len + ATT_KB - 1) / ATT_KB;
-  u32x4 rk[2], rv[2];
-  auto gload = [&](int kb) {
+  // K/V of key block j travel through register set j & 1: loaded TWO blocks ahead (at the start of block j - 2), written to
+  // the LDS stage j & 1 at the end of block j - 1 - a whole block time after the loads were issued, so the wait in front of
+  // the LDS writes finds them landed (one block ahead, the wave stood on that wait for the rest of the memory latency)
+  u32x4 rk[2][2], rv[2][2];
+  auto gload = [&](auto set, int kb) {
+    constexpr int S = decltype(set)::value;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int key = kb * ATT_KB + skey + 32 * i;
       if (key > t_len - 1) key = t_len - 1;
-      rk[i] = *(const u32x4*)(kg + (int64_t)key * ld);
-      rv[i] = *(const u32x4*)(vg + (int64_t)key * ld);
+      rk[S][i] = *(const u32x4*)(kg + (int64_t)key * ld);
+      rv[S][i] = *(const u32x4*)(vg + (int64_t)key * ld);
     }
   };
-  auto lstore = [&](int stage) {
+  auto lstore = [&](auto set, int stage) {
+    constexpr int S = decltype(set)::value;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      *(u32x4*)(smem + stage * 16384 + k_lds[i]) = rk[i];
-      *(u32x4*)(smem + stage * 16384 + v_lds[i]) = rv[i];
+      *(u32x4*)(smem + stage * 16384 + k_lds[i]) = rk[S][i];
+      *(u32x4*)(smem + stage * 16384 + v_lds[i]) = rv[S][i];
     }
   };
-  gload(0);
-  lstore(0);
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  gload(Set0{}, 0);
+  lstore(Set0{}, 0);
   __syncthreads();
 
   // K fragment read offsets: lane reads K[key = kt*32 + ql][chunk = 2*ks + hh]
@@ -97,10 +106,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void encoder_attention_kernel(const
   float m_run = -INFINITY, l_run = 0.f;
   const float sc = 0.125f * 1.44269504088896340736f;  // d_head^-0.5 * log2(e)
 
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int cur = (kb & 1) * 16384;
+  if (nkb > 1) gload(Set1{}, 1);
+  auto block = [&](auto set, int kb) {
+    constexpr int S = decltype(set)::value;       // == kb & 1
+    const int cur = S * 16384;
     const bool more = kb + 1 < nkb;
-    if (more) gload(kb + 1);
+    if (kb + 2 < nkb) gload(std::integral_constant<int, S>{}, kb + 2);      // set S held block kb: it is in LDS since the end of block kb - 1
 
     f32x16 sacc[2];
 #pragma unroll
@@ -175,8 +186,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void encoder_attention_kernel(const
         oacc[dt] = Ops::mfma32(vf.v, pf.v, oacc[dt]);
       }
     }
-    if (more) lstore((kb + 1) & 1);
+    if (more) lstore(std::integral_constant<int, 1 - S>{}, 1 - S);
     __syncthreads();
+  };
+  for (int kb = 0; kb < nkb; kb += 2) {
+    block(Set0{}, kb);
+    if (kb + 1 < nkb) block(Set1{}, kb + 1);
   }
 
   // finalise: l over both lane halves, write O[q][h*64 + dt*32 + 8g + 4hh + 0..3]
