@@ -585,7 +585,7 @@ static void dec_gemm_pick(const DecGemmParams& p, hipStream_t s) {
   // more than two rounds of the CUs, a workgroup takes four n-tiles (QKV at 96 rows: 360 workgroups -> 180; the
   // out-projections: 240 -> 60, one round).  A tile's arithmetic does not depend on which workgroup computes it.
   static const int nt4 = getenv("OHW_DEC_NT4") ? atoi(getenv("OHW_DEC_NT4")) : 1;
-  if constexpr ((LN && (EPI == DEPI_QKV || EPI == DEPI_BIAS_T || EPI == DEPI_BIAS_GELU_T)) || (!LN && EPI == DEPI_BIAS_RESID)) {
+  if constexpr ((LN && (EPI == DEPI_QKV || EPI == DEPI_BIAS_T || EPI == DEPI_BIAS_GELU_T)) || (!LN && (EPI == DEPI_BIAS_RESID || EPI == DEPI_LOGITS))) {
     const int64_t wgs = LN ? (int64_t)((n_tiles + 1) / 2) * ((mt + 1) / 2) : (int64_t)n_tiles * ((mt + 1) / 2);
     if (nt4 && mt > 2 && p.ksplit <= 1 && !p.pn && !p.stat_out && p.K <= DG_LN_MAXK && wgs > 2 * cus) { dec_gemm_launch<T, EPI, LN, 4, 2>(p, s); return; }
     // (mlp.2, K = 5120, keeps its single-tile workgroups: two tiles per workgroup measured the same within the run-to-run noise)
