@@ -133,7 +133,8 @@ int64_t ohw_dsp_resample_sinc(const float* in, int64_t n, uint32_t from_rate, ui
  *   ohw_resampler_create     builds the 256 x 256 polyphase table for from_rate -> to_rate on `device`;
  *   ohw_resampler_out_len    output samples for n input samples;
  *   ohw_resampler_run        in / out in host or device memory (in_on_device / out_on_device), on hip_stream (NULL = the
- *                            default stream); returns when host buffers may be reused, asynchronous when both are device. */
+ *                            default stream); returns when host buffers may be reused, asynchronous when both are device.
+ * One call at a time per handle (it stages host buffers in the handle's own device memory); handles are independent. */
 typedef struct ohw_resampler ohw_resampler;
 int ohw_resampler_create(int device, uint32_t from_rate, uint32_t to_rate, ohw_resampler** out);
 void ohw_resampler_free(ohw_resampler* r);
@@ -178,7 +179,8 @@ int64_t ohw_vad_run(const ohw_vad_engine* engine, const ohw_vad_config* cfg, con
  *      sequence order).  ohw_extract_chunk: AudioRecorder::extract_chunk for a 16 kHz recorder (src/input/audio.rs:737-785:
  *      nothing below 0.1 s, zero padding to 1.1 s).  ohw_chunk_scheduler_*: the chunk-timer arm of the daemon loop
  *      (src/daemon.rs:1958-2011).  Strings are UTF-8; a text returned by ohw_tracker_ready_get lives until the next
- *      take_ready on that tracker. */
+ *      take_ready on that tracker.  A tracker or scheduler is used by one thread at a time (the reference holds its tracker
+ *      inside the daemon's loop); they touch no device. */
 enum { OHW_BACKPRESSURE_WARN = 0, OHW_BACKPRESSURE_DROP_OLDEST = 1, OHW_BACKPRESSURE_DROP_NEWEST = 2 };
 typedef struct ohw_tracker ohw_tracker;
 ohw_tracker* ohw_tracker_new(int streaming);
