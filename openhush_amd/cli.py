@@ -75,8 +75,10 @@ def _transcribe_ranks(args, audio) -> int:
     p.translate = 1 if args.translate else 0
     n_win = (len(audio.samples) + E.CHUNK_SAMPLES - 1) // E.CHUNK_SAMPLES
     t1 = time.perf_counter()
-    wins = shard.transcribe_sharded(shard.engine_window_runner(ctx, args.max_batch, p), audio.samples, n_win, ctx.hp.n_text_ctx,
-                                    dist, world, rank, torch.device("cuda", local))
+    by_index = args.mel == "recording"
+    runner = shard.recording_window_runner(ctx, args.max_batch, audio.samples, p) if by_index else shard.engine_window_runner(ctx, args.max_batch, p)
+    wins = shard.transcribe_sharded(runner, audio.samples, n_win, ctx.hp.n_text_ctx, dist, world, rank, torch.device("cuda", local),
+                                    by_index=by_index)
     dt = time.perf_counter() - t1
     if rank == 0:
         text = b"".join(ctx.token_text(t) for w in wins for t in w if t < ctx.tok.eot).decode("utf-8", "replace").strip()
@@ -110,6 +112,9 @@ def main(argv=None) -> int:
     t.add_argument("--dtype", default="auto", choices=["auto", "bf16", "f16"],
                    help="auto (default): the model file's own precision - f16 for the stock ggml files (ftype 1), whose weights then stay exact")
     t.add_argument("--max-batch", type=int, default=8)
+    t.add_argument("--mel", default="window", choices=["window", "recording"],
+                   help="window (default): every 30 s cut is its own call; recording: the cuts are taken from the spectrogram of the whole "
+                        "recording (one clamp maximum, real samples across the 30 s marks), as whisper.cpp computes it for one call")
     args = ap.parse_args(argv)
 
     from . import engine as E
@@ -129,6 +134,8 @@ def main(argv=None) -> int:
     eng = E.WhisperEngine.new(args.model_path, args.language, args.translate, use_gpu, dev,
                               {"auto": E.OHW_DTYPE_AUTO, "bf16": E.OHW_DTYPE_BF16, "f16": E.OHW_DTYPE_F16}[args.dtype], args.max_batch)
     print(f"Model loaded in {1e3 * (time.perf_counter() - t0):.0f}ms", file=sys.stderr)
+    if args.mel == "recording":
+        eng.set_window_mode(E.OHW_WINDOW_FIXED_RECORDING_MEL)
     t1 = time.perf_counter()
     res = eng.transcribe(audio)
     dt = time.perf_counter() - t1

@@ -55,7 +55,7 @@ def interleave(per_rank: Sequence[List[List[int]]], n_windows: int, world: int) 
 
 
 def transcribe_sharded(transcribe_windows, pcm, n_windows: int, width: int, dist, world: int, rank: int,
-                       device: Optional[torch.device] = None):
+                       device: Optional[torch.device] = None, by_index: bool = False):
     """One long recording over `world` ranks (BASELINE.json config #4: 1 h = 120 x 30 s windows over 8 GPUs).
 
     pcm: the whole recording (1-D float32, 16 kHz), present on every rank; fixed 30 s cuts, window i -> rank i % world.
@@ -64,7 +64,8 @@ def transcribe_sharded(transcribe_windows, pcm, n_windows: int, width: int, dist
     which returns the per-window token lists in recording order (other ranks return None)."""
     chunk = 480000
     mine = assign_windows(n_windows, world, rank)
-    toks = transcribe_windows([pcm[w * chunk:(w + 1) * chunk] for w in mine]) if mine else []
+    # by_index: the runner gets window numbers (recording_window_runner cuts them from the recording it holds)
+    toks = transcribe_windows(list(mine) if by_index else [pcm[w * chunk:(w + 1) * chunk] for w in mine]) if mine else []
     if len(toks) != len(mine):
         raise RuntimeError("transcribe_windows must return one token list per window")
     rows = (n_windows + world - 1) // world             # equal shapes for the gather: pad with empty windows
@@ -94,6 +95,29 @@ def engine_window_runner(ctx, max_batch: int, params=None, mel_mode: Optional[in
                 buf[b, :len(w)] = w
                 ns.append(len(w))
             st.mel(buf, ns, mode, want=False)
+            st.encode(len(group))
+            toks, _ = st.greedy(len(group), p)
+            out += toks
+        return out
+
+    return run
+
+
+def recording_window_runner(ctx, max_batch: int, pcm, params=None):
+    """transcribe_windows for transcribe_sharded(.., by_index=True): this rank's windows are cut from the spectrogram of the
+    WHOLE recording (ohw_recording_set / ohw_mel_seek: one clamp maximum for all windows, real samples across the 30 s
+    marks - what whisper.cpp computes for a recording handed over in one call; the engine's OHW_WINDOW_FIXED_RECORDING_MEL).
+    Every rank holds the recording and finds the same maximum (a pass of the mel kernel over all frames)."""
+    from . import engine as E
+    st = E.State(ctx, max_batch)
+    p = params or ctx.default_params()
+    st.recording_set(pcm)
+
+    def run(window_ids):
+        out = []
+        for i in range(0, len(window_ids), max_batch):
+            group = list(window_ids[i:i + max_batch])
+            st.mel_seek([w * E.CHUNK_FRAMES for w in group], want=False)
             st.encode(len(group))
             toks, _ = st.greedy(len(group), p)
             out += toks
