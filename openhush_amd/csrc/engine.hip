@@ -561,6 +561,9 @@ namespace ohw {
 // the state's logit bias as the host sampler needs it (null when none is set); library-internal
 // dst reads src's recording (no copy: a view of its samples) and gets its maximum; same device; dst must not outlive src's
 // recording (the engine shares among its own states for the length of one transcribe)
+// lane states of the engine's LANES schedule: a graph capture waits until every other thread has left the library, i.e. until
+// the other lanes' decodes are over - a lane only captures where the replay clearly pays (batches below `max_batch`)
+void state_set_graph_max_batch(ohw_state* st, int max_batch) { if (st && max_batch >= 1) st->graph_max_batch = max_batch; }
 void state_share_recording(ohw_state* dst, ohw_state* src) {
   if (!dst || !src || dst == src) return;
   if (src->rec_n < 1) throw Error(OHW_E_INVALID_ARG, "share_recording: the source state holds no recording");

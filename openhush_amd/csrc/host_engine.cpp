@@ -27,6 +27,7 @@ extern thread_local std::string g_last_error;
 const float* state_bias_host(const ohw_state* st);
 void state_share_recording(ohw_state* dst, ohw_state* src);
 void state_drop_recording(ohw_state* st);
+void state_set_graph_max_batch(ohw_state* st, int max_batch);
 }
 extern "C" const ohw_ctx* ohw_state_ctx(const ohw_state* st);
 using namespace ohw;
@@ -419,7 +420,10 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
           while (rc == OHW_OK && (int)e->lane_states.size() < want_lanes) {
             ohw_state* st = nullptr;
             rc = ohw_state_create(e->ctx, e->lane_capacity, &st);
-            if (rc == OHW_OK) e->lane_states.push_back(st);
+            if (rc == OHW_OK) {
+              state_set_graph_max_batch(st, 16);      // see engine.hip: a capture on a lane waits for the other lanes' decodes
+              e->lane_states.push_back(st);
+            }
           }
           if (rc == OHW_OK && want_lanes >= 2 && (int)e->lane_streams.size() != want_lanes) {
             for (void* ls : e->lane_streams) (void)ohw_stream_destroy(ls);     // another lane count: other CU ranges
