@@ -49,9 +49,6 @@ def main():
     ap.add_argument("--pipeline", type=int, default=96,
                     help="with --phases 0 or 1: N > 0 puts two batches in flight - mel/encoder/cross-K/V of batch i+1 on N compute units "
                          "beside the decoder of batch i on the rest (round 1's schedule); 0: one batch after the other")
-    ap.add_argument("--decoders", type=int, default=1,
-                    help="with --pipeline: decodes in flight beside the front end (each on its own CU-masked stream, driven by its own "
-                         "host thread): the latency-bound GEMM chain of one decode hides under the K/V stream of the other")
     ap.add_argument("--phases", type=int, default=4,
                     help="G > 1 (default 4, the engine's LANES schedule): the front ends of G lanes (--merge batches each) run one after the other on "
                          "every CU, then G decodes side by side on G disjoint CU sets (one's latency-bound GEMM chain under the others' K/V "
@@ -169,7 +166,6 @@ def main():
         return toks
 
     pipe = None
-    D = max(1, args.decoders)
     G = max(0, args.phases)
     MG = max(1, args.merge)
     if rehearse:
@@ -245,26 +241,25 @@ def main():
             return out[-1] if n > 0 else None
     elif args.pipeline > 0 and S == 1:
         # Batches in flight on disjoint CU sets (include/ohw.h, ohw_stream_create): while batch i decodes (HBM- and
-        # latency-bound, MFMA idle) batch i+1 runs mel + encoder + cross-K/V (MFMA-bound); with --decoders 2 a second
-        # decode runs beside the first (one's GEMM chain under the other's K/V stream).  A step is still one whole
+        # latency-bound, MFMA idle) batch i+1 runs mel + encoder + cross-K/V (MFMA-bound) - round 1's schedule.  A step is still one whole
         # pass over one batch of B windows; K steps are timed from the first mel to the last token, fill and drain included.
         n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
         enc_cus = args.pipeline if args.pipeline < n_cu else max(1, n_cu * 3 // 8)     # a smaller device: the same 3 : 5 split
-        dec_cus = (n_cu - enc_cus) // D
+        dec_cus = n_cu - enc_cus
         try:
             es = E.Stream(local_rank, 0, enc_cus)
-            dss = [E.Stream(local_rank, enc_cus + l * dec_cus, dec_cus) for l in range(D)]
-            ds = dss[0]
+            ds = E.Stream(local_rank, enc_cus, dec_cus)
+            dss = [ds]
             full = E.Stream(local_rank, 0, 0)      # fill and drain run alone: every CU
-            pst = [st] + [E.State(ctx, B) for _ in range(D)]
-            pipe = {"encoder_cus": enc_cus, "decoder_cus": dec_cus, "decoders": D, "batches_in_flight": D + 1}
+            pst = [st, E.State(ctx, B)]
+            pipe = {"encoder_cus": enc_cus, "decoder_cus": dec_cus, "batches_in_flight": 2}
         except E.WhisperError as ex:               # no CU-masked queues on this box: one batch after the other
             print(f"[bench] two-batch pipeline unavailable ({ex}); running one batch after the other", file=sys.stderr, flush=True)
             pipe = None
 
     if pipe and G > 1:
         pass
-    elif pipe and D == 1:
+    elif pipe:
         def enqueue_front(s_, stream):      # asynchronous: returns as soon as the launches are queued
             s_.set_stream(stream.ptr)
             s_.mel_device(pcm.data_ptr(), pcm.shape[1], n_samples, E.OHW_MEL_ZERO_TAIL)
@@ -288,58 +283,6 @@ def main():
                 if use_dist:
                     shard.gather_tokens(shard.pack_tokens(toks, args.tokens), dist, world, rank, dev, force=True)
             return toks
-    elif pipe:
-        # D decode lanes, D + 1 states: the main thread enqueues front ends in batch order on the encoder's stream as soon as
-        # a state is free; lane l (a host thread: the greedy loop blocks its caller) decodes batches l, l + D, ... on its own
-        # CU-masked stream behind an event recorded right after that batch's front end
-        def run_steps(n):           # noqa: F811
-            if n <= 0:
-                return None
-            nS = D + 1
-            free = [threading.Semaphore(1) for _ in range(nS)]
-            ready = [threading.Event() for _ in range(n)]
-            out = [None] * n
-            err = []
-
-            def lane(l):
-                try:
-                    for i in range(l, n, D):
-                        ready[i].wait()
-                        s_ = pst[i % nS]
-                        s_.set_stream(dss[l].ptr)
-                        out[i], _ = s_.greedy(B, p)
-                        free[i % nS].release()
-                except Exception as ex:      # noqa: BLE001 - surfaced below
-                    err.append(ex)
-                    for e_ in ready:
-                        e_.set()
-                    for f_ in free:
-                        f_.release()
-
-            th = [threading.Thread(target=lane, args=(l,)) for l in range(D)]
-            for t in th:
-                t.start()
-            for i in range(n):
-                free[i % nS].acquire()
-                if err:
-                    break
-                fs = full if i == 0 else es
-                if i == 1:
-                    es.wait(full)
-                s_ = pst[i % nS]
-                s_.set_stream(fs.ptr)
-                s_.mel_device(pcm.data_ptr(), pcm.shape[1], n_samples, E.OHW_MEL_ZERO_TAIL)
-                s_.encode(B)
-                dss[i % D].wait(fs)              # this batch's cross-K/V before its decode
-                ready[i].set()
-            for t in th:
-                t.join()
-            if err:
-                raise err[0]
-            if use_dist:
-                for toks_i in out:
-                    shard.gather_tokens(shard.pack_tokens(toks_i, args.tokens), dist, world, rank, dev, force=True)
-            return out[-1]
 
     if pipe and G > 1:
         # set-up, not a step: the decode graphs are captured per (state, decode-batch size) on first use and a capture holds
