@@ -46,8 +46,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   const unsigned n_tiles_m = (unsigned)((p.M + G2_BM - 1) / G2_BM);
   const unsigned nwg = n_tiles_n * n_tiles_m;
   const unsigned lid = xcd_remap(blockIdx.x, nwg);
-  // tile order inside an XCD's contiguous range: groups of 8 m-tiles, m fastest, so that the ~32 workgroups
-  // an XCD runs at a time cover 8 m-tiles x 4 n-tiles (12 operand panels through its 4-MiB L2 instead of 17)
+  // tile order inside an XCD's contiguous range: groups of GM m-tiles (6; 8 in round 1), m fastest, so that the ~32 workgroups
+  // an XCD runs at a time cover GM m-tiles x 32 / GM n-tiles (about 12 operand panels through its 4-MiB L2 instead of 17)
   const unsigned GM = (unsigned)p.group_m;
   const unsigned per_group = GM * n_tiles_n;
   const unsigned grp_id = lid / per_group, in_grp = lid % per_group;
@@ -251,7 +251,7 @@ static void launch256_one(const GemmParams& p, hipStream_t stream) {
   ensure_dynamic_lds((const void*)gemm256_kernel<T, EPI>, 2 * G2_STAGE);
   GemmParams q = p;
   static const int gm_env = [] { const char* e = getenv("OHW_GEMM_GM"); return e ? atoi(e) : 0; }();
-  q.group_m = gm_env > 0 ? gm_env : 8;
+  q.group_m = gm_env > 0 ? gm_env : 6;   // 6: 1 % faster than 8 at 32 and at 96 windows per pass (round 2 sweep: 4, 6, 8, 16)
   hipLaunchKernelGGL((gemm256_kernel<T, EPI>), dim3(nwg), dim3(G2_THREADS), 2 * G2_STAGE, stream, q);
   HIP_CHECK(hipGetLastError());
 }
