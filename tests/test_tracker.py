@@ -110,3 +110,30 @@ def test_native_tracker_equals_the_python_mirror_on_random_traffic():
                 a.reset_dedup(); b.reset_dedup()
             assert (a.pending_count(), a.waiting_count(), a.is_empty()) == (b.pending_count(), b.waiting_count(), b.is_empty())
         b.close()
+
+
+def test_native_tracker_and_scheduler_reject_bad_arguments():
+    """the C ABI's error paths (include/ohw.h): null handles, unknown strategies, positions outside the recording"""
+    import ctypes as C
+
+    import numpy as np
+
+    from openhush_amd import engine as E
+    L = E.lib()
+    fp = C.POINTER(C.c_float)
+    rec = np.zeros(16000, np.float32)
+    assert L.ohw_tracker_add_pending(None, 0, 0, 10, 8, 0) < 0
+    t = C.c_void_p(L.ohw_tracker_new(1))
+    assert L.ohw_tracker_add_pending(t, 0, 0, 10, 8, 7) < 0                       # unknown back-pressure strategy
+    assert L.ohw_tracker_add_result(t, None, 0, 0, 0, 1.0) < 0
+    assert L.ohw_tracker_take_ready(t) == 0 and L.ohw_tracker_ready_get(t, 0, None, None, None, None, None) < 0
+    assert L.ohw_extract_chunk(rec.ctypes.data_as(fp), rec.size, 0, rec.size + 1, C.cast(None, fp), 0) < 0     # past the recording
+    assert L.ohw_extract_chunk(rec.ctypes.data_as(fp), rec.size, -1, 100, C.cast(None, fp), 0) < 0
+    assert L.ohw_extract_chunk(rec.ctypes.data_as(fp), rec.size, 8000, 4000, C.cast(None, fp), 0) == 0         # empty range: too short
+    assert not L.ohw_chunk_scheduler_new(None, 1, 10, 8, 0) and not L.ohw_chunk_scheduler_new(t, 1, 10, 8, 9)
+    s = C.c_void_p(L.ohw_chunk_scheduler_new(t, 1, 10, 8, 0))
+    assert L.ohw_chunk_scheduler_tick(s, rec.ctypes.data_as(fp), rec.size, rec.size + 5, None, None) < 0
+    assert L.ohw_chunk_scheduler_tick(s, rec.ctypes.data_as(fp), rec.size, 8000, None, None) == 17600           # 0.5 s, padded to 1.1 s
+    assert L.ohw_chunk_scheduler_position(s) == 8000 and L.ohw_chunk_scheduler_next_id(s) == 1
+    L.ohw_chunk_scheduler_free(s); L.ohw_tracker_free(t)
+    L.ohw_chunk_scheduler_free(None); L.ohw_tracker_free(None)                    # freeing nothing is fine
