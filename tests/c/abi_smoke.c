@@ -1,8 +1,8 @@
 /* The C ABI from C: include/ohw.h compiled as C99, libohw.so linked the way a C or Rust host links it.
  *   gcc -std=c99 -Wall -Werror -I include tests/c/abi_smoke.c -L openhush_amd -lohw -Wl,-rpath,$PWD/openhush_amd -lm -o abi_smoke
  * Without a GPU: `abi_smoke host` runs the host-only entry points.  With one: `abi_smoke gpu` builds a synthetic micro
- * model, transcribes a few windows through the staged API and through ohw_engine-free staged greedy, and checks that the
- * two identical windows of the batch give identical tokens. */
+ * model, runs three windows through the staged API (the two identical windows of the batch must give identical tokens) and,
+ * given a model file (`abi_smoke gpu PATH`), a 70 s recording through the product API ohw_engine_new / _transcribe. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -40,7 +40,7 @@ static int host_only(void) {
   return 0;
 }
 
-static int with_gpu(void) {
+static int with_gpu(const char* model_path) {
   ohw_hparams hp;
   memset(&hp, 0, sizeof hp);
   /* the test suite's 'micro' preset */
@@ -68,11 +68,31 @@ static int with_gpu(void) {
   printf("gpu ok: %d tokens per window, first %d, sum logprob %.3f\n", nt[0], toks[0], (double)slp[0]);
   ohw_state_free(st);
   ohw_ctx_free(ctx);
+  if (model_path) {
+    /* the product API (reference WhisperEngine::{new, transcribe}): 70 s of audio = three fixed 30 s windows, two batches */
+    ohw_engine* e = NULL;
+    CHECK(ohw_engine_new(model_path, "en", 0, 1, 0, OHW_DTYPE_AUTO, 2, &e));
+    char text[256], lang[8];
+    uint64_t ms = 0;
+    ohw_audio_info info;
+    const int64_t n_rec = 70 * 16000;
+    CHECK(ohw_engine_transcribe(e, pcm, n_rec, 16000, text, sizeof text, lang, &ms, &info));
+    const char* full = NULL;
+    size_t len = 0;
+    CHECK(ohw_engine_last_text(e, &full, &len));
+    const ohw_window_quality* q = NULL;
+    int nq = 0;
+    CHECK(ohw_engine_last_quality(e, &q, &nq));
+    if (nq != 3 || strcmp(lang, "en") != 0 || len == 0 || strncmp(full, text, strlen(text)) != 0) { fprintf(stderr, "engine: %d windows, lang %s, %zu bytes\n", nq, lang, len); return 22; }
+    printf("engine ok: %d windows, %zu bytes of text, %llu ms\n", nq, len, (unsigned long long)ms);
+    if (ohw_engine_transcribe(e, pcm, n_rec, 44100, text, sizeof text, lang, &ms, &info) != OHW_E_VALIDATION) return 23;   /* wrong rate */
+    ohw_engine_free(e);
+  }
   free(pcm);
   return 0;
 }
 
 int main(int argc, char** argv) {
-  if (argc > 1 && strcmp(argv[1], "gpu") == 0) return with_gpu();
+  if (argc > 1 && strcmp(argv[1], "gpu") == 0) return with_gpu(argc > 2 ? argv[2] : NULL);
   return host_only();
 }

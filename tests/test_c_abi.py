@@ -32,6 +32,6 @@ def test_header_compiles_as_c99_and_host_entries_work(smoke_binary):
 
 
 @pytest.mark.gpu
-def test_staged_api_from_c_on_the_gpu(smoke_binary):
-    r = subprocess.run([smoke_binary, "gpu"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "gpu ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+def test_staged_api_and_engine_from_c_on_the_gpu(smoke_binary, tmp_models):
+    r = subprocess.run([smoke_binary, "gpu", tmp_models("micro")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "gpu ok" in r.stdout and "engine ok: 3 windows" in r.stdout, (r.returncode, r.stdout, r.stderr)
