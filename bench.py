@@ -211,9 +211,13 @@ def main():
                 dbg = os.environ.get("OHW_BENCH_DEBUG") == "1"
                 tg0 = time.perf_counter(); full.sync(); tg1 = time.perf_counter()
 
+                lane_ms = [0.0] * len(lanes)
+
                 def lane(j, steps_j):
                     try:
+                        tl0 = time.perf_counter()
                         toks_j, _ = pst[j].greedy(len(steps_j) * B, p)
+                        lane_ms[j] = 1e3 * (time.perf_counter() - tl0)
                         for k, i in enumerate(steps_j):
                             out[i] = toks_j[k * B:(k + 1) * B]
                     except Exception as ex:      # noqa: BLE001
@@ -232,7 +236,8 @@ def main():
                     for j in range(len(lanes)):
                         full.wait(dss[j])            # the next group's front ends start after every decode of this one
                 if dbg:
-                    print(f"[bench] group {grp}: front ends drained after {1e3 * (tg1 - tg0):.1f} ms of waiting, decodes {1e3 * (time.perf_counter() - tg1):.1f} ms", file=sys.stderr, flush=True)
+                    print(f"[bench] group {grp}: front ends drained after {1e3 * (tg1 - tg0):.1f} ms of waiting, decodes {1e3 * (time.perf_counter() - tg1):.1f} ms "
+                          f"(lanes: {', '.join(f'{x:.0f}' for x in lane_ms)})", file=sys.stderr, flush=True)
                 if err:
                     raise err[0]
             if use_dist:
