@@ -100,8 +100,10 @@ void ohw_ctx_free(ohw_ctx* ctx); /* WhisperContext drop */
 /* ---- audio preprocessing, the step right before the path (host code: the envelope follower and the
  *      limiter are sequential recurrences over the whole recording).  In place, fp32, the reference's operation order:
  *      AudioBuffer::{rms_db, apply_gain, normalize_rms, compress, limit} (reference src/input/audio.rs:86-239),
- *      resample_linear (:972-990), TranscriptionWorker::preprocess_audio (src/queue/worker.rs:196-240).  Not built: the
- *      rubato sinc resampler and RNNoise (third-party crates). ------------------------------------------------------ */
+ *      resample_linear (:972-990), TranscriptionWorker::preprocess_audio (src/queue/worker.rs:196-240).  The rubato sinc
+ *      resampler is restated below (ohw_dsp_resample_sinc, ohw_resampler_*).  RNNoise: everything AudioBuffer::denoise
+ *      does around the network is built (ohw_dsp_denoise); the network itself (nnnoiseless 0.5.2, a third-party crate with
+ *      trained weights that is not in the reference tree) plugs in through ohw_denoise_engine. ------------------------- */
 typedef struct ohw_preprocess_config {
   int32_t preprocessing;              /* master switch, reference default 0 (src/config.rs:958,984) */
   int32_t normalization_enabled; float normalization_target_db;                       /* 1, -18 dB */
@@ -111,6 +113,24 @@ typedef struct ohw_preprocess_config {
 } ohw_preprocess_config;
 void ohw_default_preprocess_config(ohw_preprocess_config* c);
 int ohw_preprocess_audio(float* samples, int64_t n, uint32_t sample_rate, const ohw_preprocess_config* c);
+/* The noise-reduction stage of the chain (BASELINE config #5 names it; reference src/input/audio.rs:249-341, called first and
+ * independently of the `preprocessing` switch: src/queue/worker.rs:197-207).  ohw_denoise_engine is what a host plugs its
+ * nnnoiseless::DenoiseState into: process_frame takes ONE 480-sample frame at 48 kHz scaled to the 16-bit range (x 32767,
+ * as DenoiseState::process_frame does), writes 480 samples and returns the frame's voice probability; reset (may be NULL)
+ * stands for DenoiseState::new() and is called once per ohw_dsp_denoise.  ohw_dsp_denoise does the rest in the reference's
+ * order: linear resampling to 48 kHz (resample_for_rnnoise :996-1001), zero-padded last frame, first frame faded in, only
+ * the real part of a short last frame kept, linear resampling back, truncate / zero-extend to n, mix by `strength` in 0..1. */
+typedef struct ohw_denoise_engine {
+  void* user;
+  float (*process_frame)(void* user, float* out480, const float* in480);
+  void (*reset)(void* user);
+} ohw_denoise_engine;
+int ohw_dsp_denoise(float* samples, int64_t n, uint32_t sample_rate, float strength, const ohw_denoise_engine* engine);
+void ohw_denoise_passthrough_engine(ohw_denoise_engine* e);   /* out = in: the chain's framing without a network (tests) */
+/* preprocess_audio with the reference's noise_reduction settings (src/config.rs NoiseReductionConfig {enabled, strength}):
+ * enabled != 0 needs an engine (OHW_E_INVALID_ARG without one - never a silent skip) */
+int ohw_preprocess_audio_ex(float* samples, int64_t n, uint32_t sample_rate, const ohw_preprocess_config* c,
+                            int noise_reduction_enabled, float noise_reduction_strength, const ohw_denoise_engine* denoise);
 float ohw_dsp_rms_db(const float* samples, int64_t n);                 /* -inf for silence / empty */
 void ohw_dsp_apply_gain(float* samples, int64_t n, float gain_db);
 void ohw_dsp_normalize_rms(float* samples, int64_t n, float target_db);
@@ -340,7 +360,8 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* p, int n_windows, in
 
 /* additive bias on every logits row before the filter, bias[n_vocab] (host; copied), NULL clears it.  This is the
  * engine's form of whisper.cpp's logits_filter_callback (whisper_full_params; the reference sets none,
- * src/engine/whisper.rs:243-263, so the default is no bias); tests use it to make end-of-text and timestamps win. */
+ * src/engine/whisper.rs:243-263, so the default is no bias); tests use it to make end-of-text and timestamps win.
+ * Set on ohw_engine_state(e) it holds for every state ohw_engine_transcribe decodes on (the schedules' lane states too). */
 int ohw_state_set_logit_bias(ohw_state* st, const float* bias, int n);
 
 /* batch-invariant decoding (default off): the decoder picks some kernel variants from the number of rows in flight - up to
@@ -463,6 +484,13 @@ int ohw_pool_last_text(ohw_pool* p, const char** text, size_t* len);
 int ohw_pool_last_tokens(ohw_pool* p, const int32_t** tokens, int* n);
 int ohw_pool_last_quality(ohw_pool* p, const ohw_window_quality** q, int* n_windows);
 int ohw_pool_set_decode_policy(ohw_pool* p, const ohw_decode_policy* q);
+/* the window mode of EVERY engine of the pool (ohw_engine_set_window_mode): ohw_pool_transcribe rejects a pool whose engines
+ * disagree.  All three modes give the single engine's tokens: each device is handed the whole recording and cuts its own
+ * windows w, w + n, ... from it (in FIXED_RECORDING_MEL from the recording-wide spectrogram).                              */
+int ohw_pool_set_window_mode(ohw_pool* p, int mode);
+/* "" or why the RCCL broadcast was given up for peer copies.  After either kind every replica's weight buffers are compared
+ * with device_ids[0]'s (64-bit digests); a mismatch fails ohw_pool_create with OHW_E_LOAD_FAILED naming the device.          */
+const char* ohw_pool_broadcast_note(const ohw_pool* p);
 int ohw_pool_n_devices(const ohw_pool* p);
 const char* ohw_pool_broadcast_kind(const ohw_pool* p);   /* "none" (one device), "rccl" or "peer" */
 ohw_engine* ohw_pool_engine(ohw_pool* p, int i);           /* the i-th device's engine (borrowed) */
@@ -491,6 +519,10 @@ int ohw_dbg_attention(int dtype, const void* qkv, void* out, int batch, int T, i
  * logprobs_out [batch] / no_speech_out [batch] may be NULL (no-speech is defined for rows with n_hist == 0). */
 int ohw_dbg_sample(ohw_state* st, const ohw_sample_params* p, const float* logits, const int32_t* history, int hist_stride,
                    const int32_t* n_hist, int batch, int32_t* tokens_out, float* logprobs_out, float* no_speech_out);
+/* counters of a state's graph caches: "step_captures" / "beam_captures" (graphs / graph pairs captured so far),
+ * "step_graphs" / "beam_graphs" (entries held now); OHW_E_INVALID_ARG for another name.  A second ohw_greedy /
+ * ohw_beam_search with the same batch, parameters and stream must add no capture (tests/test_gpu_beam.py).        */
+int ohw_dbg_counter(const ohw_state* st, const char* name);
 
 #ifdef __cplusplus
 }

@@ -3,8 +3,8 @@
 Mirrors the reference's one-shot CLI arm (reference src/main.rs:974-1077) and its WAV input contract
 (reference src/input/audio.rs:348-434, `load_wav_file`): integer samples / 2^(bits-1), channel average, pad
 with silence to 1.1 s; prints the same JSON fields as `--format json` (src/main.rs:1054-1066).
-Only 16 kHz input is accepted here: the reference resamples with the `rubato` sinc resampler, which belongs to
-the DSP front end (out of scope).
+Any sample rate is accepted and resampled to 16 kHz (`--resampling-quality high` = the sinc resampler the reference's
+default picks, `low` = linear: reference :394-407, config.audio.resampling_quality).
 
     python -m openhush_amd.cli transcribe audio.wav --model-path /path/ggml-small.bin [--format json]
 
@@ -21,7 +21,6 @@ import os
 import struct
 import sys
 import time
-import wave
 
 import numpy as np
 
@@ -29,28 +28,61 @@ SAMPLE_RATE = 16000
 WHISPER_MIN_DURATION_SECS = 1.1   # reference src/input/audio.rs:34
 
 
-def load_wav_file(path: str) -> np.ndarray:
-    """float32 mono 16 kHz samples, padded to 1.1 s like the reference's load_wav_file."""
-    with wave.open(path, "rb") as w:
-        rate, ch, width, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
-        raw = w.readframes(n)
-    if rate != SAMPLE_RATE:
-        raise ValueError(f"{path}: {rate} Hz input needs the resampling front end (only {SAMPLE_RATE} Hz is accepted here)")
-    if width == 1:      # 8-bit WAV is unsigned; hound yields i8 = u8 - 128
-        s = (np.frombuffer(raw, np.uint8).astype(np.int32) - 128).astype(np.float32) / np.float32(1 << 7)
-    elif width == 2:
-        s = np.frombuffer(raw, "<i2").astype(np.float32) / np.float32(1 << 15)
-    elif width == 3:
-        b = np.frombuffer(raw, np.uint8).reshape(-1, 3).astype(np.int32)
+def _read_riff(path: str):
+    """(rate, channels, float32 interleaved samples) of a RIFF/WAVE file: PCM integers of 8 / 16 / 24 / 32 bits scaled by
+    2^(bits-1) and 32-bit IEEE floats as they are - the two hound::SampleFormat arms of the reference (:369-382)"""
+    with open(path, "rb") as f:
+        blob = f.read()
+    if len(blob) < 12 or blob[:4] != b"RIFF" or blob[8:12] != b"WAVE":
+        raise ValueError(f"{path}: Failed to open WAV file: no RIFF/WAVE header")
+    pos, fmt, data = 12, None, None
+    while pos + 8 <= len(blob):
+        cid, size = blob[pos:pos + 4], struct.unpack_from("<I", blob, pos + 4)[0]
+        body = blob[pos + 8:pos + 8 + size]
+        if cid == b"fmt " and len(body) >= 16:
+            fmt = body
+        elif cid == b"data":
+            data = body                      # a truncated file keeps what is there (hound's filter_map(Result::ok))
+            if fmt is not None:
+                break
+        pos += 8 + size + (size & 1)
+    if fmt is None or data is None:
+        raise ValueError(f"{path}: Failed to open WAV file: fmt or data chunk missing")
+    tag, ch, rate, _, _, bits = struct.unpack_from("<HHIIHH", fmt, 0)
+    if tag == 0xFFFE and len(fmt) >= 26:     # WAVE_FORMAT_EXTENSIBLE: the sub-format's first two bytes are the real tag
+        tag = struct.unpack_from("<H", fmt, 24)[0]
+    if ch < 1 or rate < 1:
+        raise ValueError(f"{path}: Failed to open WAV file: bad channel count or rate")
+    width = bits // 8
+    data = data[:len(data) // width * width] if width else data
+    if tag == 3 and bits == 32:
+        s = np.frombuffer(data, "<f4").astype(np.float32)
+    elif tag == 1 and width == 1:      # 8-bit WAV is unsigned; hound yields i8 = u8 - 128
+        s = (np.frombuffer(data, np.uint8).astype(np.int32) - 128).astype(np.float32) / np.float32(1 << 7)
+    elif tag == 1 and width == 2:
+        s = np.frombuffer(data, "<i2").astype(np.float32) / np.float32(1 << 15)
+    elif tag == 1 and width == 3:
+        b = np.frombuffer(data, np.uint8).reshape(-1, 3).astype(np.int32)
         v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
         v = np.where(v >= 1 << 23, v - (1 << 24), v)
         s = v.astype(np.float32) / np.float32(1 << 23)
-    elif width == 4:
-        s = np.frombuffer(raw, "<i4").astype(np.float32) / np.float32(2.0 ** 31)
+    elif tag == 1 and width == 4:
+        s = np.frombuffer(data, "<i4").astype(np.float32) / np.float32(2.0 ** 31)
     else:
-        raise ValueError(f"{path}: unsupported sample width {width}")
+        raise ValueError(f"{path}: unsupported WAV format (tag {tag}, {bits} bits)")
+    return rate, ch, s
+
+
+def load_wav_file(path: str, quality: str = "high") -> np.ndarray:
+    """float32 mono 16 kHz samples like the reference's load_wav_file (src/input/audio.rs:348-434): any rate (resampled to
+    16 kHz: `high` = the sinc resampler of :1007-1095, `low` = linear :972-990, as config.audio.resampling_quality picks -
+    the reference's default is high), any of its sample formats, channels averaged, padded with silence to 1.1 s."""
+    rate, ch, s = _read_riff(path)
     if ch > 1:   # average the channels (reference :384-391)
         s = (s[: len(s) // ch * ch].reshape(-1, ch).sum(axis=1, dtype=np.float32) / np.float32(ch)).astype(np.float32)
+    if rate != SAMPLE_RATE:              # reference :394-407
+        from . import engine as E
+        s = E.resample_sinc(s, rate, SAMPLE_RATE) if quality == "high" else E.resample_linear(s, rate, SAMPLE_RATE)
     need = int(np.float32(SAMPLE_RATE) * np.float32(WHISPER_MIN_DURATION_SECS))
     if len(s) / SAMPLE_RATE < WHISPER_MIN_DURATION_SECS:
         s = np.concatenate([s, np.zeros(need - len(s), np.float32)])
@@ -112,6 +144,8 @@ def main(argv=None) -> int:
     t.add_argument("--dtype", default="auto", choices=["auto", "bf16", "f16"],
                    help="auto (default): the model file's own precision - f16 for the stock ggml files (ftype 1), whose weights then stay exact")
     t.add_argument("--max-batch", type=int, default=8)
+    t.add_argument("--resampling-quality", default="high", choices=["low", "high"],
+                   help="for files that are not 16 kHz (the reference's config.audio.resampling_quality, default high = sinc)")
     t.add_argument("--mel", default="window", choices=["window", "recording"],
                    help="window (default): every 30 s cut is its own call; recording: the cuts are taken from the spectrogram of the whole "
                         "recording (one clamp maximum, real samples across the 30 s marks), as whisper.cpp computes it for one call")
@@ -122,8 +156,8 @@ def main(argv=None) -> int:
         print(f"error: File not found: {args.file}", file=sys.stderr)
         return 1
     try:
-        audio = E.AudioBuffer(load_wav_file(args.file), SAMPLE_RATE)
-    except (ValueError, wave.Error, EOFError) as ex:
+        audio = E.AudioBuffer(load_wav_file(args.file, args.resampling_quality), SAMPLE_RATE)
+    except (ValueError, struct.error, EOFError) as ex:
         print(f"error: {ex}", file=sys.stderr)
         return 1
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:

@@ -6,11 +6,14 @@
 //   ohw_dsp_limit           <- AudioBuffer::limit           (:197-239)
 //   ohw_dsp_resample_linear <- resample_linear              (:972-990)
 //   ohw_preprocess_audio    <- TranscriptionWorker::preprocess_audio (src/queue/worker.rs:196-240), without RNNoise
+//   ohw_dsp_denoise         <- AudioBuffer::denoise         (:249-341): the framing around the network, the network a hook
+//   ohw_preprocess_audio_ex <- preprocess_audio with its noise-reduction stage in the reference's position (worker.rs:199-207)
 // The envelope follower and the limiter are first-order recurrences with a data-dependent branch per sample over the
 //   ohw_dsp_resample_sinc   <- resample_sinc                (:1007-1095): rubato's SincFixedIn, restated from its published design
 // WHOLE recording: one sequential chain, nothing for a GPU to parallelise - they stay on the host (about 3 ns per sample).
-// Arithmetic is in fp32 in the reference's operation order.  Not built: RNNoise (the nnnoiseless crate and its trained
-// network are not under /root/reference).
+// Arithmetic is in fp32 in the reference's operation order.  Not built: the RNNoise NETWORK (the nnnoiseless 0.5.2 crate and
+// its trained weights are not under /root/reference); everything the reference does around it is, behind ohw_denoise_engine.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -235,6 +238,66 @@ void ohw_default_preprocess_config(ohw_preprocess_config* c) {
   c->compression_enabled = 1; c->compression_threshold_db = -24.0f; c->compression_ratio = 4.0f;
   c->compression_attack_ms = 5.0f; c->compression_release_ms = 50.0f; c->compression_makeup_gain_db = 6.0f;
   c->limiter_enabled = 1; c->limiter_ceiling_db = -1.0f; c->limiter_release_ms = 50.0f;
+}
+
+// AudioBuffer::denoise (reference src/input/audio.rs:249-341) around a plugged-in frame processor
+int ohw_dsp_denoise(float* s, int64_t n, uint32_t sample_rate, float strength, const ohw_denoise_engine* eng) {
+  if (!s || n < 0 || !eng || !eng->process_frame || sample_rate == 0) return OHW_E_INVALID_ARG;
+  if (n == 0 || !(strength > 0.0f)) return OHW_OK;                                   // :250-252
+  strength = strength > 1.0f ? 1.0f : strength;                                       // :254
+  constexpr uint32_t RATE = 48000;                                                    // :257-258
+  constexpr int FRAME = 480;
+  std::vector<float> up;
+  if (sample_rate != RATE) {                                                          // :267-272, resample_for_rnnoise = linear
+    up.resize((size_t)ohw_dsp_resample_linear(s, n, sample_rate, RATE, nullptr, 0));
+    (void)ohw_dsp_resample_linear(s, n, sample_rate, RATE, up.data(), (int64_t)up.size());
+  } else {
+    up.assign(s, s + n);
+  }
+  if (eng->reset) eng->reset(eng->user);                                              // a fresh DenoiseState per call (:275)
+  std::vector<float> den;
+  den.reserve(up.size());
+  float fin[FRAME], fout[FRAME];
+  for (size_t pos = 0, i = 0; pos < up.size(); pos += FRAME, ++i) {                   // :283-314
+    const size_t len = std::min<size_t>(FRAME, up.size() - pos);
+    for (size_t j = 0; j < len; ++j) fin[j] = up[pos + j] * 32767.0f;
+    for (size_t j = len; j < FRAME; ++j) fin[j] = 0.0f;
+    (void)eng->process_frame(eng->user, fout, fin);
+    if (i == 0) for (int j = 0; j < FRAME; ++j) den.push_back(fout[j] * ((float)j / (float)FRAME) / 32767.0f);   // fade-in
+    else for (size_t j = 0; j < (len < FRAME ? len : (size_t)FRAME); ++j) den.push_back(fout[j] / 32767.0f);
+  }
+  std::vector<float> down;
+  if (sample_rate != RATE) {                                                          // :317-321
+    down.resize((size_t)ohw_dsp_resample_linear(den.data(), (int64_t)den.size(), RATE, sample_rate, nullptr, 0));
+    (void)ohw_dsp_resample_linear(den.data(), (int64_t)den.size(), RATE, sample_rate, down.data(), (int64_t)down.size());
+  } else {
+    down.swap(den);
+  }
+  down.resize((size_t)n, 0.0f);                                                       // :325-326 truncate / zero-extend
+  if (strength < 1.0f) for (int64_t i = 0; i < n; ++i) s[i] = s[i] * (1.0f - strength) + down[(size_t)i] * strength;   // :329-335
+  else std::memcpy(s, down.data(), (size_t)n * sizeof(float));
+  return OHW_OK;
+}
+
+static float passthrough_frame(void*, float* out, const float* in) {
+  std::memcpy(out, in, 480 * sizeof(float));
+  return 1.0f;
+}
+void ohw_denoise_passthrough_engine(ohw_denoise_engine* e) {
+  if (!e) return;
+  e->user = nullptr; e->process_frame = passthrough_frame; e->reset = nullptr;
+}
+
+int ohw_preprocess_audio_ex(float* s, int64_t n, uint32_t sample_rate, const ohw_preprocess_config* c, int noise_reduction_enabled,
+                            float noise_reduction_strength, const ohw_denoise_engine* denoise) {
+  if (!s || !c || n < 0) return OHW_E_INVALID_ARG;
+  // noise reduction is independent of the preprocessing flag (worker.rs:197-207) and runs first
+  if (noise_reduction_enabled) {
+    if (!denoise) return OHW_E_INVALID_ARG;          // the reference would run RNNoise here: no engine plugged in is an error, not a skip
+    const int rc = ohw_dsp_denoise(s, n, sample_rate, noise_reduction_strength, denoise);
+    if (rc != OHW_OK) return rc;
+  }
+  return ohw_preprocess_audio(s, n, sample_rate, c);
 }
 
 int ohw_preprocess_audio(float* s, int64_t n, uint32_t sample_rate, const ohw_preprocess_config* c) {

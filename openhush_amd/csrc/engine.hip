@@ -3,6 +3,10 @@
 //
 // Replaces ctx.create_state() and the arithmetic inside state.full()
 // (reference src/engine/whisper.rs:167-169, 266-268).
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -22,6 +26,26 @@ ohw_ctx* ctx_synthetic(const ohw_hparams* hp, uint32_t seed, int device, int dty
 ohw_ctx* ctx_shell(const ohw_hparams* hp, int device, int dtype);
 
 thread_local std::string g_last_error;
+
+// OHW_SEGV_TRACE=1 (diagnostics): print the native frames of a SIGSEGV before the default action takes the process down -
+// the GPU debugger is not available on the pool, and a fault under a profiler or inside the runtime otherwise leaves nothing
+namespace {
+void segv_trace(int sig) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  static const char msg[] = "\n[libohw] SIGSEGV, native frames:\n";
+  (void)!write(2, msg, sizeof msg - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+struct SegvTraceInit {
+  SegvTraceInit() {
+    const char* e = getenv("OHW_SEGV_TRACE");
+    if (e && *e == '1') signal(SIGSEGV, segv_trace);
+  }
+} g_segv_trace_init;
+}  // namespace
 
 static std::shared_mutex g_api_mu;
 static thread_local int g_api_depth = 0;
@@ -102,8 +126,13 @@ struct ohw_state {
   DevBuf step_tok, n_past, tokens, n_cur, next_tok, done, n_done, sum_lp;
   // beam search (made on first use): candidates, cumulative scores, the kv_slot / token-history double buffers, finished pool
   DevBuf bm_cand_lp, bm_cand_tok, bm_sum, bm_slot[2], bm_tok2, bm_ncur, bm_npast, bm_done, bm_fin_cnt, bm_fin_tok, bm_fin_len, bm_fin_sum;
-  struct BeamGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int windows = 0, K = 0, parity = 0; SamplerParams spar{}; };
+  // one entry = the PAIR of graphs of a (windows, beam size, sampler parameters, CU budget, cross-attention variant) key: the
+  // odd and the even iteration (the token-history and kv_slot double buffers alternate); made, looked up and evicted together,
+  // so a call never holds an exec of an entry it then evicts
+  struct BeamGraph { hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t exec[2] = {nullptr, nullptr}; int windows = 0, K = 0, cus = 0; bool invariant = false; SamplerParams spar; };
   std::vector<BeamGraph> beam_graphs;
+  int step_captures = 0;
+  int beam_captures = 0;            // graph pairs captured so far (ohw_dbg_counter: a second call with the same key adds none)
   DevBuf tok_lp, nosp_prob;        // per-token log-probabilities [B][max_tokens + 1], no-speech probability [B]
   DevBuf logit_bias;               // optional f32 [n_vocab] (ohw_state_set_logit_bias)
   std::vector<float> bias_host;    // the same on the host: the temperature ladder samples there (host_engine.cpp)
@@ -378,7 +407,7 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
 
 void fill_sampler(const ohw_state* st, const ohw_sample_params* sp, int B, SamplerParams* p) {
   const ohw_ctx* c = st->ctx;
-  *p = SamplerParams{};
+  std::memset(p, 0, sizeof *p);     // every byte, padding included: the graph caches compare these structs with memcmp
   p->logits = st->logits.as<float>(); p->ld = st->logits_ld;
   p->tokens = st->tokens.as<int32_t>(); p->n_cur = st->n_cur.as<int32_t>(); p->n_past = st->n_past.as<int32_t>();
   p->next_tok = st->next_tok.as<int32_t>(); p->done = st->done.as<int32_t>(); p->n_done = st->n_done.as<int32_t>();
@@ -482,10 +511,11 @@ void ohw_state_free(ohw_state* st) {
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (g.graph) (void)hipGraphDestroy(g.graph);
   }
-  for (auto& g : st->beam_graphs) {
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    if (g.graph) (void)hipGraphDestroy(g.graph);
-  }
+  for (auto& g : st->beam_graphs)
+    for (int q = 0; q < 2; ++q) {
+      if (g.exec[q]) (void)hipGraphExecDestroy(g.exec[q]);
+      if (g.graph[q]) (void)hipGraphDestroy(g.graph[q]);
+    }
   if (st->own_stream) (void)hipStreamDestroy(st->own_stream);
   delete st;
 }
@@ -865,6 +895,7 @@ int ohw_greedy_ex(ohw_state* st, const ohw_sample_params* sp, int batch, int max
         if (ie != hipSuccess) { (void)hipGraphDestroy(ng.graph); HIP_CHECK(ie); }
         ng.batch = batch; ng.cus = st->stream_cus; ng.invariant = st->batch_invariant; ng.spar = spar;
         st->step_graphs.push_back(ng);
+        ++st->step_captures;
         step_exec = ng.exec;
       }
       int32_t n_done_host = 0;
@@ -955,10 +986,10 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* sp, int n_windows, i
     ohw_sample_params eff = *sp;
     eff.n_max = n_max;
     SamplerParams base;
-    fill_sampler(st, &eff, R, &base);
+    fill_sampler(st, &eff, R, &base);     // zeroes every byte first; advance stays 0: the beam step advances n_past itself
     int32_t* tokbuf[2] = {st->tokens.as<int32_t>(), st->bm_tok2.as<int32_t>()};
     auto params = [&](int q, SamplerParams* p, BeamParams* bp) {
-      *p = base;
+      std::memcpy(p, &base, sizeof base);
       p->tokens = tokbuf[q];
       *bp = BeamParams{};
       bp->K = K; bp->cand_lp = st->bm_cand_lp.as<float>(); bp->cand_tok = st->bm_cand_tok.as<int32_t>(); bp->beam_sum = st->bm_sum.as<float>();
@@ -980,39 +1011,61 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* sp, int n_windows, i
       // kv_slot double buffers alternate, so TWO graphs are captured (odd and even steps) and replayed in turn
       const bool use_graph = st->graphs_enabled && st->prof_class == 0 && s != nullptr;
       hipGraphExec_t exec[2] = {nullptr, nullptr};
-      for (int q = 0; q < 2 && use_graph; ++q) {
-        SamplerParams pq; BeamParams bq;
-        params(q, &pq, &bq);
+      if (use_graph) {
         for (auto& g : st->beam_graphs)
-          if (g.windows == W && g.K == K && g.parity == q && std::memcmp(&g.spar, &pq, sizeof pq) == 0) exec[q] = g.exec;
-        if (exec[q]) continue;
-        ohw_state::BeamGraph ng;
-        hipStream_t cap = st->own_stream;
-        CaptureGate gate;
-        struct StreamSwap { ohw_state* st; hipStream_t keep; ~StreamSwap() { st->stream = keep; } } swap{st, st->stream};
-        st->stream = cap;
-        HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
-        try {
-          run_decoder_step<T>(st, R, 1, st->next_tok.as<int32_t>(), K, bq.kv_slot, bq.win_done);
-          launch_beam_step(pq, bq, W, 0, cap);
-        } catch (...) {
-          hipGraph_t g = nullptr;
-          (void)hipStreamEndCapture(cap, &g);
-          if (g) (void)hipGraphDestroy(g);
-          throw;
-        }
-        HIP_CHECK(hipStreamEndCapture(cap, &ng.graph));
-        hipError_t ie = hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0);
-        if (ie != hipSuccess) { (void)hipGraphDestroy(ng.graph); HIP_CHECK(ie); }
-        ng.windows = W; ng.K = K; ng.parity = q; ng.spar = pq;
-        if (st->beam_graphs.size() >= 8) {
+          if (g.windows == W && g.K == K && g.cus == st->stream_cus && g.invariant == st->batch_invariant && std::memcmp(&g.spar, &base, sizeof base) == 0) {
+            exec[0] = g.exec[0]; exec[1] = g.exec[1];
+          }
+      }
+      if (use_graph && !exec[0]) {
+        // room first: the oldest PAIR goes before anything of this call exists (round 2 evicted the front entry between the
+        // two captures of a call - an entry whose exec the call might already hold)
+        if (st->beam_graphs.size() >= 4) {
           auto& g = st->beam_graphs.front();
-          if (g.exec) (void)hipGraphExecDestroy(g.exec);
-          if (g.graph) (void)hipGraphDestroy(g.graph);
+          for (int q = 0; q < 2; ++q) {
+            if (g.exec[q]) (void)hipGraphExecDestroy(g.exec[q]);
+            if (g.graph[q]) (void)hipGraphDestroy(g.graph[q]);
+          }
           st->beam_graphs.erase(st->beam_graphs.begin());
         }
+        ohw_state::BeamGraph ng;
+        std::memset(&ng.spar, 0, sizeof ng.spar);
+        auto drop = [&] {
+          for (int q = 0; q < 2; ++q) {
+            if (ng.exec[q]) (void)hipGraphExecDestroy(ng.exec[q]);
+            if (ng.graph[q]) (void)hipGraphDestroy(ng.graph[q]);
+          }
+        };
+        try {
+          for (int q = 0; q < 2; ++q) {
+            SamplerParams pq; BeamParams bq;
+            params(q, &pq, &bq);
+            hipStream_t cap = st->own_stream;
+            CaptureGate gate;
+            struct StreamSwap { ohw_state* st; hipStream_t keep; ~StreamSwap() { st->stream = keep; } } swap{st, st->stream};
+            st->stream = cap;
+            HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
+            try {
+              run_decoder_step<T>(st, R, 1, st->next_tok.as<int32_t>(), K, bq.kv_slot, bq.win_done);
+              launch_beam_step(pq, bq, W, 0, cap);
+            } catch (...) {
+              hipGraph_t g = nullptr;
+              (void)hipStreamEndCapture(cap, &g);
+              if (g) (void)hipGraphDestroy(g);
+              throw;
+            }
+            HIP_CHECK(hipStreamEndCapture(cap, &ng.graph[q]));
+            HIP_CHECK(hipGraphInstantiate(&ng.exec[q], ng.graph[q], nullptr, nullptr, 0));
+          }
+        } catch (...) {
+          drop();
+          throw;
+        }
+        ng.windows = W; ng.K = K; ng.cus = st->stream_cus; ng.invariant = st->batch_invariant;
+        std::memcpy(&ng.spar, &base, sizeof base);
         st->beam_graphs.push_back(ng);
-        exec[q] = ng.exec;
+        ++st->beam_captures;
+        exec[0] = ng.exec[0]; exec[1] = ng.exec[1];
       }
       int32_t n_done_host = 0;
       for (int it = 1; it < n_max; ++it) {
@@ -1075,6 +1128,16 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* sp, int n_windows, i
     }
     st->last.decode_steps = steps;
   });
+}
+
+int ohw_dbg_counter(const ohw_state* st, const char* name) {
+  if (!st || !name) return OHW_E_INVALID_ARG;
+  const std::string n = name;
+  if (n == "beam_captures") return st->beam_captures;
+  if (n == "beam_graphs") return (int)st->beam_graphs.size();
+  if (n == "step_captures") return st->step_captures;
+  if (n == "step_graphs") return (int)st->step_graphs.size();
+  return OHW_E_INVALID_ARG;
 }
 
 int ohw_state_set_batch_invariant(ohw_state* st, int on) {

@@ -172,8 +172,9 @@ ohw_engine* engine_wrap_ctx(ohw_ctx* ctx, const std::string& language, bool tran
   return e.release();
 }
 
-void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std::string* text_out) {
+void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std::string* text_out, int64_t win_first, int64_t win_step) {
   std::string& text = *text_out;
+  if (win_first < 0 || win_step < 1) throw Error(OHW_E_INVALID_ARG, "transcribe: window dealing must be first >= 0, step >= 1");
     ohw_sample_params sp;
     ohw_default_sample_params(e->ctx, &sp);
     // reference :246-248: "auto" skips set_language and whisper.cpp keeps its default "en"
@@ -341,23 +342,28 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
       // host-side windowing: fixed 30 s cuts (BASELINE.json north_star).  Each cut is its own `full` call in
       // whisper.cpp terms: seek 0, its own frame count as the end of the audio, a fresh generator - and, like a call with
       // less than 1 s of audio (`seek + 100 >= seek_end` before the first window), a cut of at most 100 frames yields nothing
-      const int64_t n_win = (n + CHUNK_SAMPLES - 1) / CHUNK_SAMPLES;
+      // the pool deals the recording's windows round-robin: this engine takes windows win_first, win_first + win_step, ... of
+      // the WHOLE recording it is handed (no copy, and - FIXED_RECORDING_MEL - the real neighbouring samples and the
+      // recording-wide clamp maximum); k counts this engine's windows, rec_win(k) is the window of the recording
+      const int64_t n_win_rec = (n + CHUNK_SAMPLES - 1) / CHUNK_SAMPLES;
+      const int64_t n_win = n_win_rec > win_first ? (n_win_rec - win_first + win_step - 1) / win_step : 0;
+      auto rec_win = [&](int64_t k) { return win_first + k * win_step; };
       const int64_t n_batches = (n_win + e->max_batch - 1) / e->max_batch;
       auto batch_of = [&](int64_t bi) { return (int)std::min<int64_t>(e->max_batch, n_win - bi * e->max_batch); };
       // windows w0 .. w0 + B of the recording into st: each cut on its own (its own `full()` call), or cut from the spectrogram
       // of the whole recording (FIXED_RECORDING_MEL: st reads the recording e->state holds)
       const bool rec_mel = e->window_mode == OHW_WINDOW_FIXED_RECORDING_MEL;
       auto mel_windows = [&](ohw_state* st, int64_t w0, int B, const int32_t* nsv) {
-        if (!rec_mel) { check(ohw_mel(st, samples + w0 * CHUNK_SAMPLES, CHUNK_SAMPLES, nsv, B, 0, OHW_MEL_ZERO_TAIL, nullptr)); return; }
+        if (!rec_mel) { check(ohw_mel(st, samples + rec_win(w0) * CHUNK_SAMPLES, win_step * CHUNK_SAMPLES, nsv, B, 0, OHW_MEL_ZERO_TAIL, nullptr)); return; }
         std::vector<int32_t> seeks((size_t)B);
-        for (int b = 0; b < B; ++b) seeks[(size_t)b] = (int32_t)((w0 + b) * CHUNK_FRAMES);
+        for (int b = 0; b < B; ++b) seeks[(size_t)b] = (int32_t)(rec_win(w0 + b) * CHUNK_FRAMES);
         check(ohw_mel_seek(st, seeks.data(), B, nullptr));
       };
       if (rec_mel) check(ohw_recording_set(e->state, samples, n, 0, nullptr));
       auto fill_ns = [&](int64_t bi, std::vector<int32_t>& nsv) {
         const int64_t w0 = bi * e->max_batch;
         const int B = batch_of(bi);
-        for (int b = 0; b < B; ++b) nsv[(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + b) * CHUNK_SAMPLES);
+        for (int b = 0; b < B; ++b) nsv[(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - rec_win(w0 + b) * CHUNK_SAMPLES);
       };
       auto front = [&](int64_t bi, ohw_state* st, void* stream, std::vector<int32_t>& nsv) {
         fill_ns(bi, nsv);
@@ -475,6 +481,21 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
           for (ohw_state* st : e->lane_states) state_drop_recording(st);
         }
       } shared_recording(e, rec_mel);
+      // the logit bias of the engine's own state (ohw_state_set_logit_bias on ohw_engine_state(e): the engine's form of
+      // whisper.cpp's logits_filter_callback) applies to every state a schedule decodes on, or to none
+      {
+        const float* bias = state_bias_host(e->state);
+        const int V_ = e->ctx->hp.n_vocab;
+        auto same = [&](ohw_state* st) {
+          if (st == e->state) return;
+          const float* b2 = state_bias_host(st);
+          if (!bias && !b2) return;
+          if (bias && b2 && std::memcmp(bias, b2, (size_t)V_ * sizeof(float)) == 0) return;
+          check(ohw_state_set_logit_bias(st, bias, bias ? V_ : 0));
+        };
+        for (ohw_state* st : e->states) same(st);
+        for (ohw_state* st : e->lane_states) same(st);
+      }
       auto restore = [&] {
         for (ohw_state* st : e->states) (void)ohw_state_set_stream(st, nullptr);
         for (ohw_state* st : e->lane_states) (void)ohw_state_set_stream(st, nullptr);
@@ -554,7 +575,7 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
               check(ohw_state_set_stream(st, e->s_full));
               // ONE front-end pass over all the lane's windows (its state holds them): the encoder's GEMMs run in rounds of
               // 256 tiles of 256 rows, and 96 windows (563 row tiles) fill their last round where 32 (188) leave it 2/3 empty
-              for (int b = 0; b < Wd; ++b) nss[(size_t)j][(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - (w0 + b) * CHUNK_SAMPLES);
+              for (int b = 0; b < Wd; ++b) nss[(size_t)j][(size_t)b] = (int32_t)std::min<int64_t>(CHUNK_SAMPLES, n - rec_win(w0 + b) * CHUNK_SAMPLES);
               mel_windows(st, w0, Wd, nss[(size_t)j].data());
               check(ohw_encode(st, Wd));
             }

@@ -37,5 +37,7 @@ namespace ohw {
 // an engine around an already loaded context (takes ownership of ctx on success); throws Error
 ohw_engine* engine_wrap_ctx(ohw_ctx* ctx, const std::string& language, bool translate, int max_batch, int device);
 // the path after validation: windows, decode policy, text assembly (untrimmed text in *text); fills the engine's last_* records
-void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std::string* text);
+// win_first / win_step (fixed-cut modes only): the engine takes windows win_first, win_first + win_step, ... of the recording
+// (the pool's round-robin deal); the records it leaves (last_tokens / last_quality) list its own windows in that order
+void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std::string* text, int64_t win_first = 0, int64_t win_step = 1);
 }  // namespace ohw

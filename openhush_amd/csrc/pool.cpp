@@ -37,6 +37,7 @@ struct ohw_pool {
   std::vector<int> devices;
   std::string language;
   std::string last_text, broadcast;    // broadcast: "none" | "rccl" | "peer"
+  std::string broadcast_note;          // why RCCL was given up, if it was
   std::vector<int32_t> last_tokens;
   std::vector<ohw_window_quality> last_quality;
 };
@@ -85,38 +86,60 @@ struct Rccl {
   }
 };
 
-// the weight arena and the filterbank of ctxs[0] into every other context
-std::string broadcast_weights(const std::vector<ohw_ctx*>& ctxs, const std::vector<int>& devs) {
-  ApiScope api;
-  const int n = (int)ctxs.size();
-  if (n == 1) return "none";
-  const bool distinct = std::set<int>(devs.begin(), devs.end()).size() == devs.size();
-  const char* mode = getenv("OHW_POOL_BCAST");
-  Rccl r;
-  if (distinct && !(mode && std::string(mode) == "peer") && r.load()) {
-    std::vector<ncclComm_t> comms((size_t)n);
-    if (r.CommInitAll(comms.data(), n, devs.data()) == ncclSuccess) {
-      bool ok = true;
-      for (int part = 0; part < 2 && ok; ++part) {
-        ok = r.GroupStart() == ncclSuccess;
-        for (int i = 0; i < n && ok; ++i) {
-          HIP_CHECK(hipSetDevice(devs[(size_t)i]));
-          const DevBuf& src = part == 0 ? ctxs[0]->arena : ctxs[0]->mel_filters;
-          const DevBuf& dst = part == 0 ? ctxs[(size_t)i]->arena : ctxs[(size_t)i]->mel_filters;
-          ok = r.Broadcast(i == 0 ? src.p : dst.p, dst.p, src.bytes, ncclUint8, 0, comms[(size_t)i], nullptr) == ncclSuccess;
-        }
-        ok = (r.GroupEnd() == ncclSuccess) && ok;
-      }
-      for (int i = 0; i < n; ++i) {
-        HIP_CHECK(hipSetDevice(devs[(size_t)i]));
-        HIP_CHECK(hipDeviceSynchronize());
-        (void)r.CommDestroy(comms[(size_t)i]);
-      }
-      if (ok) return "rccl";
-      throw Error(OHW_E_LOAD_FAILED, "pool: RCCL broadcast of the weight blob failed");
+// every resident weight buffer of ctxs[i] against ctxs[0] (64-bit digests, a few ms per device): a broadcast that returned
+// success but left other bytes on a device would otherwise surface as garbage transcripts on that device only
+void verify_replicas(const std::vector<ohw_ctx*>& ctxs, const std::vector<int>& devs, const char* kind) {
+  char name[64];
+  for (int idx = 0;; ++idx) {
+    uint64_t d0 = 0;
+    if (ohw_ctx_weight_digest(ctxs[0], idx, name, &d0) != OHW_OK) break;        // past the last buffer
+    for (size_t i = 1; i < ctxs.size(); ++i) {
+      uint64_t di = 0;
+      char nm[64];
+      if (ohw_ctx_weight_digest(ctxs[i], idx, nm, &di) != OHW_OK || di != d0)
+        throw Error(OHW_E_LOAD_FAILED, std::string("pool: device ") + std::to_string(devs[i]) + " holds other bytes than device " + std::to_string(devs[0]) +
+                                           " in weight buffer '" + name + "' after the " + kind + " broadcast");
     }
   }
-  // peer-to-peer copies (also the path for a device listed twice: a plain device-to-device copy)
+}
+
+// RCCL communicators of one ncclCommInitAll, destroyed on every path out
+struct Comms {
+  Rccl& r;
+  std::vector<ncclComm_t> c;
+  const std::vector<int>& devs;
+  bool live = false;
+  Comms(Rccl& r_, const std::vector<int>& d) : r(r_), c(d.size(), nullptr), devs(d) {}
+  ~Comms() {
+    if (!live) return;
+    for (size_t i = 0; i < c.size(); ++i) {
+      (void)hipSetDevice(devs[i]);
+      (void)hipDeviceSynchronize();
+      if (c[i]) (void)r.CommDestroy(c[i]);
+    }
+  }
+};
+
+// One grouped broadcast of `bytes` from ctxs[0]'s buffer into the same buffer of every other context; false on ANY error
+// (RCCL's or HIP's) with the group closed again - the caller then falls back to peer copies.
+// NOTE: this branch has never executed (no box with two distinct devices was available to any round): it is written to the
+// RCCL documentation's single-process pattern and guarded by the fallback and by verify_replicas.
+bool rccl_broadcast(Rccl& r, Comms& cm, const std::vector<ohw_ctx*>& ctxs, int part) {
+  const int n = (int)ctxs.size();
+  if (r.GroupStart() != ncclSuccess) return false;
+  bool ok = true;
+  for (int i = 0; i < n && ok; ++i) {
+    const DevBuf& src = part == 0 ? ctxs[0]->arena : ctxs[0]->mel_filters;
+    const DevBuf& dst = part == 0 ? ctxs[(size_t)i]->arena : ctxs[(size_t)i]->mel_filters;
+    ok = hipSetDevice(cm.devs[(size_t)i]) == hipSuccess &&
+         r.Broadcast(i == 0 ? src.p : dst.p, dst.p, src.bytes, ncclUint8, 0, cm.c[(size_t)i], nullptr) == ncclSuccess;
+  }
+  const bool closed = r.GroupEnd() == ncclSuccess;      // always: an open group would swallow every later RCCL call
+  return ok && closed;
+}
+
+void peer_copies(const std::vector<ohw_ctx*>& ctxs, const std::vector<int>& devs) {
+  const int n = (int)ctxs.size();
   for (int i = 1; i < n; ++i) {
     HIP_CHECK(hipSetDevice(devs[(size_t)i]));
     if (devs[(size_t)i] != devs[0]) {
@@ -128,6 +151,40 @@ std::string broadcast_weights(const std::vector<ohw_ctx*>& ctxs, const std::vect
     HIP_CHECK(hipMemcpyPeer(ctxs[(size_t)i]->mel_filters.p, devs[(size_t)i], ctxs[0]->mel_filters.p, devs[0], ctxs[0]->mel_filters.bytes));
     HIP_CHECK(hipDeviceSynchronize());
   }
+}
+
+// the weight arena and the filterbank of ctxs[0] into every other context: RCCL when the devices are distinct and the library
+// loads; on ANY RCCL failure - and for a device listed twice - peer-to-peer copies; either way every replica is verified
+std::string broadcast_weights(const std::vector<ohw_ctx*>& ctxs, const std::vector<int>& devs, std::string* note) {
+  ApiScope api;
+  const int n = (int)ctxs.size();
+  if (n == 1) return "none";
+  const bool distinct = std::set<int>(devs.begin(), devs.end()).size() == devs.size();
+  const char* mode = getenv("OHW_POOL_BCAST");
+  Rccl r;
+  if (distinct && !(mode && std::string(mode) == "peer") && r.load()) {
+    bool ok = false;
+    {
+      Comms cm(r, devs);
+      if (r.CommInitAll(cm.c.data(), n, devs.data()) == ncclSuccess) {
+        cm.live = true;
+        ok = rccl_broadcast(r, cm, ctxs, 0) && rccl_broadcast(r, cm, ctxs, 1);
+      }
+    }                                                  // communicators synchronised and destroyed here, whatever happened
+    (void)hipGetLastError();
+    if (ok) {
+      try {
+        verify_replicas(ctxs, devs, "rccl");
+        return "rccl";
+      } catch (const Error& e) {
+        if (note) *note = e.what();                    // wrong bytes after a "successful" broadcast: try the copies
+      }
+    } else if (note) {
+      *note = "RCCL broadcast failed, fell back to peer copies";
+    }
+  }
+  peer_copies(ctxs, devs);
+  verify_replicas(ctxs, devs, "peer");
   return "peer";
 }
 
@@ -156,16 +213,26 @@ int ohw_pool_create(const char* model_path, const char* language, int translate,
       for (ohw_ctx* c : ctxs) if (c) ohw_ctx_free(c);
     };
     try {
+      int n_dev = 0;
+      if (hipGetDeviceCount(&n_dev) != hipSuccess) n_dev = 0;
+      for (int i = 0; i < n_devices; ++i)            // before the 3 GB file read: a bad id names itself
+        if (device_ids[i] < 0 || device_ids[i] >= n_dev)
+          throw Error(OHW_E_NO_GPU, "pool: device " + std::to_string(device_ids[i]) + " (entry " + std::to_string(i) + " of the device list) does not exist: " +
+                                        std::to_string(n_dev) + " device(s) visible");
       int rc = ohw_ctx_create(model_path, device_ids[0], dtype, &ctxs[0]);      // the one file read
-      if (rc != OHW_OK) throw Error(rc == OHW_E_NO_GPU || rc == OHW_E_OOM ? rc : OHW_E_LOAD_FAILED, "Failed to load model: " + g_last_error);
+      if (rc != OHW_OK) throw Error(rc == OHW_E_NO_GPU || rc == OHW_E_OOM ? rc : OHW_E_LOAD_FAILED, "pool: device " + std::to_string(device_ids[0]) + ": Failed to load model: " + g_last_error);
       ohw_hparams hp;
       (void)ohw_ctx_info(ctxs[0], &hp, nullptr);
       dtype = ohw_ctx_dtype(ctxs[0]);                       // what OHW_DTYPE_AUTO resolved to
       for (int i = 1; i < n_devices; ++i) {
         rc = ohw_ctx_create_shell(&hp, device_ids[i], dtype, &ctxs[(size_t)i]);
-        if (rc != OHW_OK) throw Error(rc, "pool: device " + std::to_string(device_ids[i]) + ": " + g_last_error);
+        if (rc != OHW_OK) throw Error(rc, "pool: device " + std::to_string(device_ids[i]) + " (entry " + std::to_string(i) + " of the device list): " + g_last_error);
       }
-      p->broadcast = broadcast_weights(ctxs, p->devices);
+      try {
+        p->broadcast = broadcast_weights(ctxs, p->devices, &p->broadcast_note);
+      } catch (const Error& e) {
+        throw Error(e.code, std::string("pool: weight broadcast: ") + e.what());
+      }
       for (int i = 0; i < n_devices; ++i) {
         ohw_engine* e = engine_wrap_ctx(ctxs[(size_t)i], lang, translate != 0, max_batch, device_ids[i]);
         ctxs[(size_t)i] = nullptr;                 // owned by the engine now
@@ -189,6 +256,16 @@ int ohw_pool_n_devices(const ohw_pool* p) { return p ? (int)p->engines.size() : 
 const char* ohw_pool_broadcast_kind(const ohw_pool* p) { return p ? p->broadcast.c_str() : ""; }
 ohw_engine* ohw_pool_engine(ohw_pool* p, int i) { return (p && i >= 0 && i < (int)p->engines.size()) ? p->engines[(size_t)i] : nullptr; }
 
+int ohw_pool_set_window_mode(ohw_pool* p, int mode) {
+  if (!p) return OHW_E_INVALID_ARG;
+  for (ohw_engine* e : p->engines) {
+    const int rc = ohw_engine_set_window_mode(e, mode);
+    if (rc != OHW_OK) return rc;
+  }
+  return OHW_OK;
+}
+const char* ohw_pool_broadcast_note(const ohw_pool* p) { return p ? p->broadcast_note.c_str() : ""; }
+
 int ohw_pool_set_decode_policy(ohw_pool* p, const ohw_decode_policy* q) {
   if (!p || !q) return OHW_E_INVALID_ARG;
   for (ohw_engine* e : p->engines) (void)ohw_engine_set_decode_policy(e, q);
@@ -210,25 +287,22 @@ int ohw_pool_transcribe(ohw_pool* p, const float* samples, int64_t n, uint32_t s
     const auto t0 = std::chrono::steady_clock::now();
     const int G = (int)p->engines.size();
     const int64_t n_win = (n + CHUNK_SAMPLES - 1) / CHUNK_SAMPLES;
-    // window w -> device w % G; a device's windows, in order, as one contiguous buffer: only the recording's last window can
-    // be short and it is the last of its device's list, so the engine's own fixed 30 s cuts reproduce the same windows
-    std::vector<std::vector<float>> bufs((size_t)G);
+    const int mode = p->engines[0]->window_mode;
+    for (ohw_engine* e : p->engines)
+      if (e->window_mode != mode) throw Error(OHW_E_INVALID_ARG, "pool: the engines disagree on the window mode (use ohw_pool_set_window_mode)");
+    // window w -> device w % G.  Every engine is handed the WHOLE recording (borrowed, not copied) and the arithmetic
+    // progression of windows it owns (engine_transcribe_core: first g, step G): its windows are cut at the recording's own
+    // 30 s marks - and in FIXED_RECORDING_MEL from the spectrogram of the whole recording - exactly as a single engine cuts them
     std::vector<std::string> errs((size_t)G);
     std::vector<std::thread> th;
-    const bool seek = p->engines[0]->window_mode == OHW_WINDOW_SEEK;     // the seek loop is sequential by nature: device 0 alone
+    const bool seek = mode == OHW_WINDOW_SEEK;     // the seek loop is sequential by nature: device 0 alone
     const int used = seek ? 1 : (int)std::min<int64_t>(G, n_win);
     for (int g = 0; g < used; ++g) {
-      if (!seek && G > 1) {
-        for (int64_t w = g; w < n_win; w += G) {
-          const int64_t off = w * CHUNK_SAMPLES, len = std::min<int64_t>(CHUNK_SAMPLES, n - off);
-          bufs[(size_t)g].insert(bufs[(size_t)g].end(), samples + off, samples + off + len);
-        }
-      }
       th.emplace_back([&, g] {
         try {
           std::string text;
-          if (!seek && G > 1) engine_transcribe_core(p->engines[(size_t)g], bufs[(size_t)g].data(), (int64_t)bufs[(size_t)g].size(), &text);
-          else engine_transcribe_core(p->engines[(size_t)g], samples, n, &text);
+          if (seek) engine_transcribe_core(p->engines[(size_t)g], samples, n, &text);
+          else engine_transcribe_core(p->engines[(size_t)g], samples, n, &text, g, used);
         } catch (const std::exception& ex) {
           errs[(size_t)g] = ex.what()[0] ? ex.what() : "unknown error";
         }

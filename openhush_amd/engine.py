@@ -80,6 +80,15 @@ class SpeechSegment(C.Structure):
     _fields_ = [("start", C.c_int64), ("end", C.c_int64), ("avg_probability", C.c_float)]
 
 
+DENOISE_FRAME_FN = C.CFUNCTYPE(C.c_float, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float))
+DENOISE_RESET_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class DenoiseEngineC(C.Structure):
+    """ohw_denoise_engine: where a host plugs in nnnoiseless::DenoiseState (reference src/input/audio.rs:275-293)"""
+    _fields_ = [("user", C.c_void_p), ("process_frame", DENOISE_FRAME_FN), ("reset", DENOISE_RESET_FN)]
+
+
 VAD_PROCESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_float))
 VAD_RESET_FN = C.CFUNCTYPE(None, C.c_void_p)
 
@@ -132,6 +141,8 @@ EXPORTS = [
     "ohw_vad_state_is_speech", "ohw_vad_state_speech_start", "ohw_vad_state_reset", "ohw_vad_energy_engine", "ohw_vad_energy_engine_free",
     "ohw_vad_run",
     "ohw_pool_create", "ohw_pool_transcribe", "ohw_pool_last_text", "ohw_pool_last_tokens", "ohw_pool_last_quality",
+    "ohw_dbg_counter", "ohw_dsp_denoise", "ohw_denoise_passthrough_engine", "ohw_preprocess_audio_ex", "ohw_pool_set_window_mode",
+    "ohw_pool_broadcast_note",
     "ohw_pool_set_decode_policy", "ohw_pool_n_devices", "ohw_pool_broadcast_kind", "ohw_pool_engine", "ohw_pool_free",
 ]
 
@@ -196,6 +207,13 @@ def lib():
         L.ohw_default_preprocess_config.argtypes = [C.POINTER(PreprocessConfig)]
         L.ohw_default_preprocess_config.restype = None
         L.ohw_preprocess_audio.argtypes = [fp, C.c_int64, C.c_uint32, C.POINTER(PreprocessConfig)]
+        L.ohw_dsp_denoise.argtypes = [fp, C.c_int64, C.c_uint32, C.c_float, C.POINTER(DenoiseEngineC)]
+        L.ohw_denoise_passthrough_engine.argtypes = [C.POINTER(DenoiseEngineC)]
+        L.ohw_denoise_passthrough_engine.restype = None
+        L.ohw_preprocess_audio_ex.argtypes = [fp, C.c_int64, C.c_uint32, C.POINTER(PreprocessConfig), C.c_int, C.c_float, C.POINTER(DenoiseEngineC)]
+        L.ohw_pool_set_window_mode.argtypes = [vp, C.c_int]
+        L.ohw_pool_broadcast_note.argtypes = [vp]
+        L.ohw_pool_broadcast_note.restype = C.c_char_p
         L.ohw_dsp_rms_db.argtypes = [fp, C.c_int64]
         L.ohw_dsp_rms_db.restype = C.c_float
         L.ohw_dsp_apply_gain.argtypes = [fp, C.c_int64, C.c_float]
@@ -329,6 +347,7 @@ def lib():
         L.ohw_ctx_weight_digest.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(C.c_uint64)]
         L.ohw_dbg_gemm.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, vp]
         L.ohw_dbg_attention.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+        L.ohw_dbg_counter.argtypes = [vp, C.c_char_p]
         _lib = L
     return _lib
 
@@ -537,6 +556,13 @@ class State:
 
     def set_stream(self, stream_ptr: Optional[int]):
         _check(lib().ohw_state_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+
+    def counter(self, name: str) -> int:
+        """ohw_dbg_counter: step_captures, beam_captures, step_graphs, beam_graphs"""
+        v = int(lib().ohw_dbg_counter(self.h, name.encode()))
+        if v < 0:
+            raise ValueError(name)
+        return v
 
     def mel(self, pcm: np.ndarray, n_samples: Optional[Sequence[int]] = None, mode: int = OHW_MEL_REFLECT, want: bool = True):
         """pcm: [B][stride] float32 host array"""
@@ -762,12 +788,51 @@ class AudioBuffer:
         b = self._buf()
         return int(lib().ohw_dsp_limit(_fp(b), b.size, self.sample_rate, ceiling_db, release_ms)) if b.size else 0
 
-    def preprocess(self, config: Optional["PreprocessConfig"] = None):
-        """TranscriptionWorker::preprocess_audio (reference src/queue/worker.rs:196-240) without RNNoise"""
+    def preprocess(self, config: Optional["PreprocessConfig"] = None, noise_reduction: bool = False, strength: float = 1.0,
+                   denoiser: Optional["Denoiser"] = None):
+        """TranscriptionWorker::preprocess_audio (reference src/queue/worker.rs:196-240): noise reduction first and
+        independently of the preprocessing switch (needs a Denoiser: the network is the host's), then the chain"""
         b = self._buf()
         cfg = config or default_preprocess_config()
-        if b.size:
+        if not b.size:
+            return
+        if noise_reduction:
+            if denoiser is None:
+                raise WhisperError(OHW_E_INVALID_ARG, "noise reduction is enabled but no denoise engine is plugged in")
+            _check(lib().ohw_preprocess_audio_ex(_fp(b), b.size, self.sample_rate, C.byref(cfg), 1, strength, C.byref(denoiser.c)))
+        else:
             _check(lib().ohw_preprocess_audio(_fp(b), b.size, self.sample_rate, C.byref(cfg)))
+
+    def denoise(self, strength: float, denoiser: "Denoiser"):
+        """AudioBuffer::denoise (reference src/input/audio.rs:249-341) with the plugged-in frame processor"""
+        b = self._buf()
+        if b.size:
+            _check(lib().ohw_dsp_denoise(_fp(b), b.size, self.sample_rate, strength, C.byref(denoiser.c)))
+
+
+class Denoiser:
+    """ohw_denoise_engine around a Python callable frame(float32[480]) -> float32[480] (the stand-in for
+    nnnoiseless::DenoiseState::process_frame); Denoiser() without a callable is the library's pass-through engine"""
+
+    def __init__(self, process_frame=None, reset=None):
+        self.c = DenoiseEngineC()
+        self.frames = 0
+        if process_frame is None:
+            lib().ohw_denoise_passthrough_engine(C.byref(self.c))
+            return
+
+        def _frame(_user, out, inp):
+            self.frames += 1
+            res = np.asarray(process_frame(np.ctypeslib.as_array(inp, shape=(480,)).copy()), dtype=np.float32)
+            np.ctypeslib.as_array(out, shape=(480,))[:] = res
+            return 1.0
+
+        def _reset(_user):
+            if reset:
+                reset()
+        self._keep = (DENOISE_FRAME_FN(_frame), DENOISE_RESET_FN(_reset))
+        self.c.user = None
+        self.c.process_frame, self.c.reset = self._keep
 
 
 def default_preprocess_config() -> PreprocessConfig:
@@ -1060,6 +1125,16 @@ class EnginePool:
     @property
     def broadcast_kind(self) -> str:
         return lib().ohw_pool_broadcast_kind(self.h).decode()
+
+    @property
+    def broadcast_note(self) -> str:
+        return lib().ohw_pool_broadcast_note(self.h).decode()
+
+    def set_window_mode(self, mode: int):
+        _check(lib().ohw_pool_set_window_mode(self.h, mode))
+
+    def engine_handle(self, i: int):
+        return lib().ohw_pool_engine(self.h, i)
 
     def set_decode_policy(self, **kw):
         pol = DecodePolicy()

@@ -128,36 +128,61 @@ def native_extract_chunk(recording: np.ndarray, from_pos: int, to_pos: int) -> O
 
 
 class StreamingSession:
-    """Chunks of one recording through the MI355X path.  beam_size 0 = greedy; vad: callable samples -> probability (the
-    VadEngine hook) with `vad_threshold`, or None."""
+    """Chunks of one recording through the MI355X path, in the worker's stage order (reference src/queue/worker.rs:119-193):
+    noise reduction (the RNNoise stage of BASELINE config #5: a plugged-in `denoiser`, reference src/input/audio.rs:249-341) ->
+    normalise / compress / limit when `audio_config.preprocessing` is on (:196-240) -> VAD gate -> every 30 s window of the
+    job through mel -> encoder -> beam search or greedy -> text.  beam_size 0 = greedy; vad: callable samples -> probability
+    (the VadEngine hook) with `vad_threshold`, or None."""
 
     def __init__(self, ctx: E.Context, beam_size: int = 5, vad: Optional[Callable[[np.ndarray], float]] = None, vad_threshold: float = 0.5,
-                 sequence_id: int = 1, tracker: Optional[TranscriptionTracker] = None, params: Optional[E.SampleParams] = None):
+                 sequence_id: int = 1, tracker: Optional[TranscriptionTracker] = None, params: Optional[E.SampleParams] = None,
+                 audio_config: Optional[E.PreprocessConfig] = None, noise_reduction: bool = False, noise_reduction_strength: float = 1.0,
+                 denoiser: Optional["E.Denoiser"] = None):
         self.ctx = ctx
         self.beam_size = beam_size
-        self.state = E.State(ctx, max(1, beam_size))          # one window per chunk: beam_size decoder rows
+        self.state = E.State(ctx, max(1, beam_size))          # one window at a time: beam_size decoder rows
         self.vad, self.vad_threshold = vad, vad_threshold
         self.tracker = tracker or TranscriptionTracker()
         self.scheduler = ChunkScheduler(self.tracker, sequence_id)
         self.params = params or ctx.default_params()
+        self.audio_config = audio_config
+        self.noise_reduction, self.noise_reduction_strength, self.denoiser = noise_reduction, noise_reduction_strength, denoiser
+        if noise_reduction and denoiser is None:
+            raise E.WhisperError(E.OHW_E_INVALID_ARG, "noise reduction is enabled but no denoise engine is plugged in")
         self.skipped_silent = 0
+        self.windows_decoded = 0
 
     def _text(self, tokens: List[int]) -> str:
         return b"".join(self.ctx.token_text(t) for t in tokens if t < self.ctx.tok.eot).decode("utf-8", "replace").strip()
 
+    def preprocess(self, samples: np.ndarray) -> np.ndarray:
+        """TranscriptionWorker::preprocess_audio on a copy of the job's buffer"""
+        if not self.noise_reduction and (self.audio_config is None or not self.audio_config.preprocessing):
+            return samples
+        buf = E.AudioBuffer(np.array(samples, dtype=np.float32, order="C"), SAMPLE_RATE)
+        buf.preprocess(self.audio_config, self.noise_reduction, self.noise_reduction_strength, self.denoiser)
+        return buf.samples
+
     def transcribe_job(self, job: ChunkJob) -> ChunkResult:
-        s = job.samples[:E.CHUNK_SAMPLES]
-        if self.vad is not None and float(self.vad(s)) < self.vad_threshold:
+        s_all = self.preprocess(job.samples)
+        if self.vad is not None and float(self.vad(s_all)) < self.vad_threshold:
             self.skipped_silent += 1
             text = ""
         else:
-            self.state.mel(s[None, :], [len(s)], E.OHW_MEL_ZERO_TAIL, want=False)
-            self.state.encode(1)
-            if self.beam_size >= 2:
-                toks = self.state.beam_search(1, self.beam_size, self.params)[0]["tokens"]
-            else:
-                toks = self.state.greedy(1, self.params)[0][0]
-            text = self._text(toks)
+            # the worker hands the WHOLE buffer to engine.transcribe (worker.rs:152): a job longer than 30 s (a late timer
+            # tick, a long VAD segment in continuous mode) is cut at the 30 s marks like any other input, window after window
+            parts = []
+            for off in range(0, len(s_all), E.CHUNK_SAMPLES):
+                s = s_all[off:off + E.CHUNK_SAMPLES]
+                self.state.mel(s[None, :], [len(s)], E.OHW_MEL_ZERO_TAIL, want=False)
+                self.state.encode(1)
+                if self.beam_size >= 2:
+                    toks = self.state.beam_search(1, self.beam_size, self.params)[0]["tokens"]
+                else:
+                    toks = self.state.greedy(1, self.params)[0][0]
+                parts.append(b"".join(self.ctx.token_text(t) for t in toks if t < self.ctx.tok.eot))
+                self.windows_decoded += 1
+            text = b"".join(parts).decode("utf-8", "replace").strip()
         return ChunkResult(text, job.sequence_id, job.chunk_id, job.is_final, len(job.samples) / SAMPLE_RATE)
 
     def tick(self, recording: np.ndarray, current_pos: int, is_final: bool = False) -> List[ChunkResult]:

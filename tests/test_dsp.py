@@ -95,3 +95,79 @@ def test_preprocess_audio_chain_and_defaults():
     c = E.AudioBuffer(x.copy())
     c.preprocess(cfg)
     assert np.allclose(c.samples, O.normalize_rms(x, -18.0), rtol=2e-6, atol=1e-9)
+
+
+# ---- the sinc resampler against an independent fp64 checker (oracle/dsp.py; rubato 0.16.2 is not in the reference tree:
+#      PARITY UNPINNED against the crate itself) ----------------------------------------------------------------------------
+@pytest.mark.parametrize("rates", [(48000, 16000), (44100, 16000), (8000, 16000), (22050, 16000), (96000, 16000), (11025, 16000)])
+def test_host_sinc_resampler_matches_the_fp64_oracle(rates):
+    fr, to = rates
+    rng = np.random.default_rng(fr)
+    for n in (1, 255, 1024, 1025, 3000, int(fr * 0.9)):               # below one chunk, exact chunks, ragged tails
+        t = np.arange(n) / fr
+        x = (0.4 * np.sin(2 * np.pi * 440.0 * t) + 0.2 * np.sin(2 * np.pi * 3100.0 * t + 0.3) + 0.05 * rng.standard_normal(n)).astype(np.float32)
+        want = O.resample_sinc(x, fr, to)
+        got = E.resample_sinc(x, fr, to)
+        assert got.size == want.size == O.sinc_out_len(n, to / fr), (rates, n, got.size, want.size)
+        # fp32 sums of 2 x 256 products against fp64: observed <= 1e-6 on O(1) signals
+        assert np.abs(got - want).max() < 3e-6 * max(1.0, float(np.abs(want).max())), (rates, n, float(np.abs(got - want).max()))
+    assert E.resample_sinc(np.zeros(0, np.float32), fr, to).size == 0 and O.resample_sinc(np.zeros(0), fr, to).size == 0
+
+
+def test_sinc_table_is_a_unit_gain_low_pass():
+    """what the checker itself must satisfy: every one of the 256 sub-filters sums to 1 within the table's own ripple (DC gain
+    1 at every fractional position) and the table is symmetric about its centre tap"""
+    for ratio in (1 / 3, 16000 / 44100, 2.0):
+        h = O.sinc_table64(ratio).reshape(O.SINC_L, O.SINC_F)
+        assert np.abs(h.sum(axis=0) - 1.0).max() < 2e-3
+        flat = h.reshape(-1)
+        assert np.abs(flat[1:] - flat[1:][::-1]).max() < 1e-12
+
+
+# ---- the RNNoise stage without the network (reference src/input/audio.rs:249-341; worker.rs:197-207) ---------------------
+def test_denoise_framing_matches_the_oracle_bit_for_bit():
+    rng = np.random.default_rng(9)
+    x = (0.2 * rng.standard_normal(16000 * 2 + 137)).astype(np.float32)        # 201 frames at 48 kHz, the last one short
+    seen = []
+
+    def net(frame):                                   # stands for DenoiseState::process_frame: sees 16-bit-range samples
+        seen.append(float(np.abs(frame).max()))
+        return (frame * np.float32(0.5)).astype(np.float32)
+    for strength in (1.0, 0.4, 7.0):                  # 7.0 clamps to 1.0 (:254)
+        a = E.AudioBuffer(x.copy(), 16000)
+        d = E.Denoiser(net)
+        a.denoise(strength, d)
+        assert d.frames == 201
+        assert np.array_equal(a.samples, O.denoise(x, 16000, strength, net)), strength
+    assert max(seen) > 1000.0                         # frames really are scaled by 32767
+    # pass-through engine: the up / down linear resampling alone, first 10 ms faded in
+    a = E.AudioBuffer(x.copy(), 16000)
+    a.denoise(1.0, E.Denoiser())
+    assert np.array_equal(a.samples, O.denoise(x, 16000, 1.0, lambda f: f))
+    assert np.abs(a.samples[400:-400] - x[400:-400]).max() < 1e-6 and abs(a.samples[0]) < 1e-6 and len(a.samples) == len(x)
+    # strength <= 0 and an empty buffer leave the samples alone (:250-252); a 48 kHz buffer is not resampled
+    b = E.AudioBuffer(x.copy(), 16000); b.denoise(0.0, E.Denoiser(net)); assert np.array_equal(b.samples, x)
+    c = E.AudioBuffer(x[:4800].copy(), 48000); c.denoise(1.0, E.Denoiser(net))
+    assert np.array_equal(c.samples, O.denoise(x[:4800], 48000, 1.0, net))
+
+
+def test_preprocess_runs_noise_reduction_first_and_independently_of_the_switch():
+    """worker.rs:197-211: denoise when noise_reduction.enabled, whatever `preprocessing` says; then the chain"""
+    x = _sine(0.05, 8000)
+    half = lambda f: (f * np.float32(0.5)).astype(np.float32)     # noqa: E731
+    off = E.default_preprocess_config()                           # preprocessing = 0
+    a = E.AudioBuffer(x.copy(), 16000)
+    a.preprocess(off, noise_reduction=True, strength=1.0, denoiser=E.Denoiser(half))
+    assert np.array_equal(a.samples, O.denoise(x, 16000, 1.0, half))
+    on = E.default_preprocess_config(); on.preprocessing = 1
+    b = E.AudioBuffer(x.copy(), 16000)
+    b.preprocess(on, noise_reduction=True, strength=1.0, denoiser=E.Denoiser(half))
+    c = E.AudioBuffer(O.denoise(x, 16000, 1.0, half), 16000)
+    c.preprocess(on)
+    assert np.array_equal(b.samples, c.samples)
+    with pytest.raises(E.WhisperError):                           # enabled without an engine: an error, never a silent skip
+        E.AudioBuffer(x.copy(), 16000).preprocess(on, noise_reduction=True)
+    import ctypes as C
+    buf = x.copy()
+    assert E.lib().ohw_preprocess_audio_ex(E._fp(buf), buf.size, 16000, C.byref(on), 1, 1.0, None) == E.OHW_E_INVALID_ARG
+    assert np.array_equal(buf, x)

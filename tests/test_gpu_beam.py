@@ -84,3 +84,44 @@ def test_beam_search_matches_oracle(E, oracle, tmp_models, dt):
     assert exact >= 0.7 * total
     with pytest.raises(E.WhisperError):
         E.State(ctx, 4).beam_search(1, 5)              # no encode / too few decoder rows
+
+
+def test_beam_graph_pairs_are_cached_evicted_whole_and_never_recaptured(E, tmp_models):
+    """The beam step's two graphs (odd / even iteration) are ONE cache entry: a second call with the same (windows, beams,
+    parameters, stream, cross-attention variant) adds no capture; another variant is another key; and filling the cache past its
+    four pairs evicts whole pairs while every call keeps returning what its first run returned (round 2 could evict the entry
+    whose first graph the call already held: engine.hip, ohw_beam_search)."""
+    ctx = E.Context.from_file(tmp_models("micro"), 0, E.OHW_DTYPE_F16)
+    K = 3
+    st = E.State(ctx, 2 * K)
+    pcm = np.stack([synth.synth_audio(s) for s in (3, 11)])
+    st.mel(pcm, None, E.OHW_MEL_ZERO_TAIL, want=False)
+    st.encode(2)
+    first = {}
+    assert st.counter("beam_captures") == 0 and st.counter("beam_graphs") == 0
+    for n_max in (8, 9, 10, 11, 12, 13):                 # six keys through a cache of four pairs
+        p = ctx.default_params(); p.n_max = n_max
+        before = st.counter("beam_captures")
+        first[n_max] = st.beam_search(2, K, p)
+        assert st.counter("beam_captures") == before + 1
+        assert st.beam_search(2, K, p) == first[n_max]
+        assert st.counter("beam_captures") == before + 1, "the second call with the same key captured again"
+    assert st.counter("beam_graphs") == 4
+    for n_max in (13, 8, 12, 9, 8, 13):                  # hits and misses interleaved: evictions happen between uses
+        p = ctx.default_params(); p.n_max = n_max
+        assert st.beam_search(2, K, p) == first[n_max], n_max
+    p = ctx.default_params(); p.n_max = 13
+    before = st.counter("beam_captures")
+    st.set_batch_invariant(True)                         # another cross-attention variant: must not replay the other one's graph
+    inv = st.beam_search(2, K, p)
+    assert st.counter("beam_captures") == before + 1
+    st.set_batch_invariant(False)
+    assert [len(x["tokens"]) for x in inv] == [len(x["tokens"]) for x in first[13]]
+    # the greedy cache counts the same way
+    g0 = st.counter("step_captures")
+    q = ctx.default_params(); q.n_max = 12
+    a = st.greedy(2, q); c1 = st.counter("step_captures"); b = st.greedy(2, q)
+    assert a[0] == b[0] and c1 == g0 + 1 and st.counter("step_captures") == c1
+    with pytest.raises(ValueError):
+        st.counter("no such counter")
+    st.close()

@@ -210,13 +210,14 @@ def test_config4_one_hour_120_windows_on_one_gpu(E, large_v3_file, monkeypatch):
     assert len(out["0"][0]) > 0
 
 
-def test_large_v3_window_result_does_not_depend_on_its_batch(E, large_v3_file):
-    """Size-independent property at BASELINE dimensions: 40 large-v3 windows decoded as one 40-row batch on a 64-CU stream (a
-    LANES lane: four n-tiles per workgroup in the decoder GEMMs) against the same windows as batches of 32 + 8 on the whole
-    chip - logits of the prompt pass and of a single-token step, greedy tokens and their log-probabilities, bit for bit
-    (ohw_state_set_batch_invariant; what makes every schedule of ohw_engine_transcribe give the same tokens)."""
+@pytest.mark.parametrize("n", [40, 96])
+def test_large_v3_window_result_does_not_depend_on_its_batch(E, large_v3_file, n):
+    """Size-independent property at BASELINE dimensions: n large-v3 windows decoded as one n-row batch on a 64-CU stream (a
+    LANES lane: four n-tiles per workgroup in the decoder GEMMs; n = 96 is the bench's own lane shape, three front-end batches
+    merged into one decode) against the same windows as batches of at most 32 on the whole chip - logits of the prompt pass and
+    of a single-token step, greedy tokens and their log-probabilities, bit for bit (ohw_state_set_batch_invariant; what makes
+    every schedule of ohw_engine_transcribe give the same tokens)."""
     ctx = E.Context.from_file(large_v3_file, 0, E.OHW_DTYPE_BF16)
-    n = 40
     pcm = np.stack([synth.synth_audio(3000 + w) for w in range(n)])
     tok = ctx.tok
     prompt = np.asarray([tok.sot, tok.sot + 1, tok.transcribe, tok.no_timestamps], np.int32)
@@ -231,7 +232,7 @@ def test_large_v3_window_result_does_not_depend_on_its_batch(E, large_v3_file):
     G = big.greedy_ex(n, p)
     small = E.State(ctx, 32)
     small.set_batch_invariant(True)
-    for f, m in ((0, 32), (32, 8)):
+    for f, m in [(f, min(32, n - f)) for f in range(0, n, 32)]:
         small.mel(pcm[f:f + m], None, E.OHW_MEL_ZERO_TAIL, want=False); small.encode(m)
         l0 = small.decode(np.tile(prompt, (m, 1)), [0] * m)
         l1 = small.decode(l0.argmax(axis=1).astype(np.int32)[:, None], [4] * m)
@@ -285,3 +286,87 @@ def test_config4_two_ranks_share_the_gpu_at_large_v3_dims(E, large_v3_file):
         pr.join(timeout=120)
         assert pr.exitcode == 0
     assert got == ref and all(len(t) == 48 for t in got)
+
+
+# ---- BASELINE config #5 at its own size: large-v3 dims, one 5 s chunk, beam = 5, the hipGraph-captured beam step -----------
+# logit biases picked on the oracle (CPU, round 3): with (4, 9) the five beams finish after 3 and 6 tokens and the winner is a
+# 6-token sequence (finished candidates of two lengths ranked by log-probability per token); with (5, 8) two beams finish
+# early and the others run to n_max = 16 (the live beams join the finished pool)
+CFG5_BIAS, CFG5_BIAS_LONG = (4.0, 9.0), (5.0, 8.0)
+
+
+def _cfg5_bias(n_vocab, tok_beg, tok_eot, ts_eot=CFG5_BIAS):
+    b = np.zeros(n_vocab, np.float32)
+    b[tok_beg:] = ts_eot[0]
+    b[tok_eot] = ts_eot[1]
+    return b
+
+
+def test_config5_large_v3_beam5_chunk_against_oracle_and_its_properties(E, oracle, monkeypatch):
+    """large-v3 dimensions (procedural weights, bf16), one 5 s chunk zero-padded to a window, beam = 5, n_max 16, a logit bias
+    that lets timestamps and end-of-text occur.  (a) against oracle.beam_search: the oracle's exact winner, or a sequence
+    that scores as well under the ORACLE's own scoring (beam search ranks 30 candidates by cumulative log-probability: a bf16
+    near-tie may legitimately pick another one; tests/test_gpu_beam.py holds the same rule at micro dims).  (b) properties
+    at this size: two consecutive calls identical (graph replay); graphs on == graphs off (OHW_GRAPHS=0: every iteration
+    launched kernel by kernel); a window's beams do not depend on another window in the batch."""
+    hp = synth.PRESETS["large-v3"]
+    oracle.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    om = oracle.Model.synth(hp.as_list(), 1234)
+    ctx = E.Context.synthetic(hp.as_list(), 1234, 0, E.OHW_DTYPE_BF16)
+    K, n_max = 5, 16
+    bias = _cfg5_bias(om.n_vocab, om.tok_beg, om.tok_eot)
+    chunk = synth.synth_audio(21)[:80000]                      # 5 s
+    other = synth.synth_audio(22)[:80000]
+    p = ctx.default_params(); p.n_max = n_max
+    st = E.State(ctx, 2 * K)
+    st.set_logit_bias(bias)
+    mel = st.mel(np.stack([chunk, other]), [80000, 80000], E.OHW_MEL_ZERO_TAIL)
+    st.encode(2)
+    both = st.beam_search(2, K, p)
+    caps = st.counter("beam_captures")
+    assert st.beam_search(2, K, p) == both and st.counter("beam_captures") == caps == 1          # (b1) replay, no re-capture
+    # (b3) window 0 alone, in a state of its own
+    st1 = E.State(ctx, K)
+    st1.set_logit_bias(bias)
+    st1.mel(chunk[None, :], [80000], E.OHW_MEL_ZERO_TAIL, want=False)
+    st1.encode(1)
+    alone = st1.beam_search(1, K, p)[0]
+    assert alone == both[0], (alone, both[0])
+    # (b2) graphs off: the state reads OHW_GRAPHS when it is made
+    monkeypatch.setenv("OHW_GRAPHS", "0")
+    st0 = E.State(ctx, K)
+    monkeypatch.delenv("OHW_GRAPHS")
+    st0.set_logit_bias(bias)
+    st0.mel(chunk[None, :], [80000], E.OHW_MEL_ZERO_TAIL, want=False)
+    st0.encode(1)
+    assert st0.beam_search(1, K, p)[0] == alone and st0.counter("beam_captures") == 0
+    # the same three properties where the search runs to n_max with finished and live beams mixed (GPU only: the oracle
+    # needs 90 s of 8 cores for this one)
+    long_bias = _cfg5_bias(om.n_vocab, om.tok_beg, om.tok_eot, CFG5_BIAS_LONG)
+    for s_ in (st, st1, st0):
+        s_.set_logit_bias(long_bias)
+    both_l = st.beam_search(2, K, p)
+    assert st.beam_search(2, K, p) == both_l and st.counter("beam_captures") == 1
+    alone_l = st1.beam_search(1, K, p)[0]
+    assert alone_l == both_l[0] and st0.beam_search(1, K, p)[0] == alone_l
+    assert max(len(x["tokens"]) for x in both_l) > len(alone["tokens"])
+    # (a) the oracle on the same window (its own mel and encoder: fp32)
+    ref_mel = om.log_mel(chunk, 1)
+    assert np.abs(mel[0] - ref_mel).max() < 2e-4
+    enc = om.encode(ref_mel)
+    op = om.default_params(); op.n_max = n_max
+    ref = oracle.beam_search(om, enc, op, K, bias)
+    g = both[0]
+    print(f"config#5 beam=5: gpu {g['tokens']} (finished {g['n_finished']}, sum {g['sum_logprob']:.3f}); oracle {ref['tokens']} "
+          f"(finished {ref['n_finished']}, sum {ref['sum_logprob']:.3f})")
+    assert len(g["tokens"]) > 0 and ref["n_finished"] > 0
+    if g["tokens"] == ref["tokens"]:
+        assert abs(g["sum_logprob"] - ref["sum_logprob"]) < 0.5 * max(1, len(g["tokens"])) ** 0.5
+    else:
+        s = oracle.State(om); s.set_encoder_output(enc)
+        best = max(c[1] / max(1, len(c[0])) for c in ref["candidates"])
+        mine = max(s.score_sequence(op, g["tokens"], e, bias) / max(1, len(g["tokens"])) for e in (True, False))
+        assert mine > best - 0.1, (g, ref["tokens"], mine, best)
+    ts = [t for t in g["tokens"] if t >= om.tok_beg]
+    assert ts == sorted(ts)
+    st.close(); st1.close(); st0.close(); om.close()

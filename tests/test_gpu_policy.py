@@ -269,8 +269,56 @@ def test_pool_behind_the_c_abi(E, tmp_models):
         pool.close()
     with pytest.raises(E.ModelNotFound):
         E.EnginePool(path + ".missing", "auto", False, [0])
-    with pytest.raises(E.WhisperError):
+    with pytest.raises(E.WhisperError) as bad:
         E.EnginePool(path, "auto", False, [0, 7])           # no such device on this box
+    assert "device 7" in str(bad.value) and "entry 1" in str(bad.value)      # the failing device names itself
+
+
+def test_pool_deals_windows_by_index_in_every_window_mode(E, tmp_models):
+    """ohw_pool_transcribe == ohw_engine_transcribe token for token in all three window modes, with device 0 listed 2x and 3x:
+    every engine is handed the whole recording and cuts its own windows w, w + G, ... (round 2 concatenated a device's
+    windows into one buffer: in FIXED_RECORDING_MEL the clamp maximum and the samples at the 30 s marks then came from the
+    wrong neighbours).  Dealing cases: n_win < G, n_win = G + 1 with a short last window, an exact multiple, one window."""
+    path = tmp_models("micro")
+    # loud / quiet windows so that the recording-wide clamp matters; 4 windows + a 2 s tail
+    scale = (1.0, 0.05, 0.6, 0.02, 0.8)
+    pcm = np.concatenate([np.float32(scale[w]) * synth.synth_audio(90 + w) for w in range(4)] + [np.float32(scale[4]) * synth.synth_audio(95, 32000)])
+    recs = {"5w_short_tail": pcm, "2w": pcm[:2 * 480000], "3w_exact": pcm[:3 * 480000], "1w": pcm[:300000], "4w_plus_1s": pcm[:4 * 480000 + 16000]}
+    bias = np.zeros(51865, np.float32); bias[50364:] = 6.0; bias[50257] = 27.0      # timestamps and end-of-text occur: the seek loop moves
+    for mode in (E.OHW_WINDOW_FIXED, E.OHW_WINDOW_FIXED_RECORDING_MEL, E.OHW_WINDOW_SEEK):
+        eng = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_F16, 2)
+        eng.set_decode_policy(temperature_inc=0.0)
+        eng.set_window_mode(mode)
+        E.State.set_logit_bias(_Borrowed(E, eng.state_h), bias)
+        ref = {}
+        for name, r in recs.items():
+            res = eng.transcribe(E.AudioBuffer(r, 16000))
+            ref[name] = (res.text, eng.last_tokens(), [q[0] for q in eng.last_quality()])
+        eng.close()
+        for devices in ([0, 0], [0, 0, 0]):
+            pool = E.EnginePool(path, "auto", False, devices, E.OHW_DTYPE_F16, 2)
+            pool.set_decode_policy(temperature_inc=0.0)
+            pool.set_window_mode(mode)
+            for i in range(len(devices)):
+                E.State.set_logit_bias(_Borrowed(E, E.lib().ohw_engine_state(pool.engine_handle(i))), bias)
+            for name, r in recs.items():
+                res = pool.transcribe(E.AudioBuffer(r, 16000))
+                got = (res.text, pool.last_tokens(), pool.last_window_tokens())
+                assert got == ref[name], (mode, devices, name)
+            pool.close()
+    # engines that disagree on the mode are refused
+    pool = E.EnginePool(path, "auto", False, [0, 0], E.OHW_DTYPE_F16, 2)
+    E.lib().ohw_engine_set_window_mode(pool.engine_handle(1), E.OHW_WINDOW_FIXED_RECORDING_MEL)
+    with pytest.raises(E.WhisperError):
+        pool.transcribe(E.AudioBuffer(pcm, 16000))
+    pool.close()
+
+
+class _Borrowed:
+    """a state handle owned by an engine, for State's methods"""
+    def __init__(self, E, h):
+        import ctypes as C
+        self.h = h if isinstance(h, C.c_void_p) else C.c_void_p(h)
 
 
 def test_fixed_cuts_on_the_recording_wide_spectrogram(E, oracle, tmp_models):

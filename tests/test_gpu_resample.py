@@ -1,7 +1,8 @@
-"""The sinc resampler on the device (include/ohw.h, ohw_resampler_*) against the host restatement of the
-reference's resample(.., ResamplingQuality::High) (ohw_dsp_resample_sinc; reference src/input/audio.rs:1007-1095): the same
-number of samples and the same samples up to the order of the fp32 sums, for the capture rates the reference meets; then the
-48 kHz -> 16 kHz output feeds the log-mel without leaving the device."""
+"""The sinc resampler on the device (include/ohw.h, ohw_resampler_*) against the ORACLE's independent fp64
+restatement of the reference's resample(.., ResamplingQuality::High) (oracle/dsp.py resample_sinc; reference
+src/input/audio.rs:1007-1095; rubato 0.16.2 itself is not in the reference tree: parity unpinned against the crate) and
+against the library's host version: the same number of samples and the same samples up to fp32 summation, for the capture
+rates the reference meets; then the 48 kHz -> 16 kHz output feeds the log-mel without leaving the device."""
 import numpy as np
 import pytest
 
@@ -34,11 +35,16 @@ def test_device_resampler_matches_host(E, rates):
     rs = E.DeviceResampler(fr, to)
     for n in (1, 700, 1024, 1025, 5000, int(fr * 3.3)):            # below one chunk, exact chunks, a ragged tail
         x = _tone(fr, 4.0, n)[:n]
+        from oracle import dsp as O
+        ref = O.resample_sinc(x, fr, to)                 # the checker: fp64, written independently of both product versions
         want = E.resample_sinc(x, fr, to)
         got = rs.run(x)
-        assert got.size == want.size == rs.out_len(n), (rates, n, got.size, want.size)
+        assert got.size == want.size == ref.size == rs.out_len(n) == O.sinc_out_len(n, to / fr), (rates, n, got.size, want.size, ref.size)
         if want.size:
-            assert np.abs(got - want).max() < 2e-6 * max(1.0, float(np.abs(want).max())), (rates, n, float(np.abs(got - want).max()))
+            scale = max(1.0, float(np.abs(ref).max()))
+            assert np.abs(got - ref).max() < 3e-6 * scale, (rates, n, float(np.abs(got - ref).max()))       # device vs oracle
+            assert np.abs(want - ref).max() < 3e-6 * scale, (rates, n, float(np.abs(want - ref).max()))     # host vs oracle
+            assert np.abs(got - want).max() < 2e-6 * scale, (rates, n, float(np.abs(got - want).max()))
     assert rs.out_len(0) == 0
     rs.close()
 

@@ -106,6 +106,53 @@ def test_streaming_session_matches_single_windows(tmp_models, beam):
     assert any(r.text for r in out)
 
 
+@pytest.mark.gpu
+def test_streaming_job_longer_than_30s_and_the_noise_reduction_stage(tmp_models):
+    """(i) A job longer than 30 s (a late timer tick, a long VAD segment) is transcribed whole, window after window - the
+    reference's worker hands the whole buffer to engine.transcribe (src/queue/worker.rs:152); round 2 dropped everything after
+    30 s.  (ii) BASELINE config #5's stage order with a plugged-in denoiser: noise reduction -> (normalise / compress / limit)
+    -> VAD -> decode, i.e. what reaches the engine is the preprocessed buffer (reference worker.rs:147-152, 197-240)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible")
+    from openhush_amd import engine as E
+    ctx = E.Context.from_file(tmp_models("micro"), 0, E.OHW_DTYPE_F16)
+    p = ctx.default_params(); p.n_max = 12
+    rec = np.concatenate([synth.synth_audio(31), synth.synth_audio(32), synth.synth_audio(33)[:16000 * 7]])       # 67 s
+    ses = S.StreamingSession(ctx, beam_size=0, sequence_id=5, params=p)
+    out = ses.tick(rec, len(rec), is_final=True)                       # ONE tick after 67 s: one job of three windows
+    assert len(out) == 1 and ses.windows_decoded == 3 and abs(out[0].duration_secs - 67.0) < 1e-6
+    st = E.State(ctx, 1)
+    parts = []
+    for off in range(0, len(rec), E.CHUNK_SAMPLES):
+        s = rec[off:off + E.CHUNK_SAMPLES]
+        st.mel(s[None, :], [len(s)], E.OHW_MEL_ZERO_TAIL, want=False); st.encode(1)
+        parts.append(b"".join(ctx.token_text(t) for t in st.greedy(1, p)[0][0] if t < ctx.tok.eot))
+    assert out[0].text == b"".join(parts).decode("utf-8", "replace").strip() and len(parts[2]) > 0
+    # (ii) the denoiser halves every frame, then the chain normalises to -18 dB: the engine must see exactly that buffer
+    cfg = E.default_preprocess_config(); cfg.preprocessing = 1
+    half = lambda f: (f * np.float32(0.5)).astype(np.float32)           # noqa: E731
+    chunk = synth.synth_audio(41)[:16000 * 5]
+    seen = []
+
+    def vad(s):
+        seen.append(np.array(s))
+        return 1.0
+    ses2 = S.StreamingSession(ctx, beam_size=5, vad=vad, sequence_id=6, params=p, audio_config=cfg, noise_reduction=True,
+                              noise_reduction_strength=1.0, denoiser=E.Denoiser(half))
+    got = ses2.tick(chunk, len(chunk), is_final=True)
+    want_buf = E.AudioBuffer(chunk.copy(), 16000)
+    want_buf.preprocess(cfg, True, 1.0, E.Denoiser(half))
+    assert np.array_equal(seen[0], want_buf.samples) and not np.array_equal(seen[0], chunk)
+    st5 = E.State(ctx, 5)
+    st5.mel(want_buf.samples[None, :], [len(chunk)], E.OHW_MEL_ZERO_TAIL, want=False); st5.encode(1)
+    toks = st5.beam_search(1, 5, p)[0]["tokens"]
+    assert got[0].text == b"".join(ctx.token_text(t) for t in toks if t < ctx.tok.eot).decode("utf-8", "replace").strip()
+    with pytest.raises(E.WhisperError):
+        S.StreamingSession(ctx, noise_reduction=True)                   # enabled without an engine
+    st.close(); st5.close()
+
+
 def test_energy_vad_hook_gates_silence():
     from openhush_amd import engine as E
     v = E.EnergyVad(-40.0)
