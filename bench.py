@@ -57,6 +57,12 @@ def main():
                     help="with --phases: batches (steps) one lane takes through ONE front-end pass and ONE decode of merge x batch "
                          "windows - the decoder streams its weights once per token whatever its batch, and 96 windows fill the "
                          "encoder GEMMs' last round of 256-row tiles")
+    ap.add_argument("--pool", action="store_true",
+                    help="ONE process drives --gpus devices through the C ABI's ohw_pool_* (ncclCommInitAll + one broadcast of the weight "
+                         "arena, windows dealt round-robin, host gather): the design BASELINE.json's north_star describes.  Launch plainly "
+                         "(python bench.py --pool --gpus N), not under torch.distributed.run; host PCM in (PCIe-inclusive)")
+    ap.add_argument("--pool-devices", default="", help="with --pool: explicit device list, e.g. 0,0 to rehearse two engines on one card")
+    ap.add_argument("--no-latency", action="store_true", help="skip the small-batch latency figures (large-v3 B = 1, config #2, config #5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=0, help="decode tokens in the CPU sample (0 = same as --tokens)")
     ap.add_argument("--cpu-windows", type=int, default=2, help="30 s windows in the CPU sample")
@@ -65,6 +71,8 @@ def main():
     import torch
     from openhush_amd import engine as E, shard, synth
 
+    if args.pool:
+        return pool_bench(args, torch, E, synth)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal of the N > 1 path on a ONE-GPU box: OHW_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo (RCCL needs
@@ -177,7 +185,10 @@ def main():
             dss = [E.Stream(local_rank, l * (n_cu // G), n_cu // G) for l in range(G)]
             es = ds = full
             pst = [E.State(ctx, B * MG) for _ in range(G)]
-            pcm_rep = pcm.repeat(MG, 1) if MG > 1 else pcm       # a lane's windows: MG steps of the same B synthetic windows
+            # every window in flight is its own synthetic recording: lane j's decode batch = windows [j * MG * B, (j + 1) * MG * B)
+            # of this rank's G * MG * B (window ids are global: rank * G * MG * B + ...)
+            n_fl = G * MG * B
+            pcm_all = torch.from_numpy(np.stack([synth.synth_audio(rank * n_fl + w) for w in range(n_fl)])).cuda() if n_fl > B else pcm
             pipe = {"schedule": "lanes", "decoders_side_by_side": G, "batches_per_decode": MG, "decoder_cus": n_cu // G,
                     "batches_in_flight": G * MG}
         except E.WhisperError as ex:
@@ -204,7 +215,7 @@ def main():
                     # ONE front-end pass over the lane's len(steps_j) x B windows (the engine does the same): 96 windows fill
                     # the last round of the encoder GEMMs' 256-row tiles where 32 leave it two thirds empty
                     c = len(steps_j)
-                    s_.mel_device(pcm_rep.data_ptr(), pcm_rep.shape[1], n_samples * c, E.OHW_MEL_ZERO_TAIL)
+                    s_.mel_device(pcm_all.data_ptr() + j * MG * B * pcm_all.shape[1] * 4, pcm_all.shape[1], n_samples * c, E.OHW_MEL_ZERO_TAIL)
                     s_.encode(c * B)
                 # the host waits for the group's front ends before it starts the lane threads: lanes that begin to enqueue
                 # their decode while the front ends still run cost 6 % of a step (283.9 against 261.7 - 268.2 ms, measured)
@@ -375,6 +386,9 @@ def main():
         roof.update({"kernel": PROF_NAMES[prof_class], "launches": launches, "avg_launch_us": round(1e3 * k_ms / max(1, launches), 2),
                      "kernel_ms_per_step": round(k_ms / args.steps, 3),
                      "class_ms_per_step": {PROF_NAMES[k]: round(v, 3) for k, v in class_totals.items()}})
+        latency = None
+        if world == 1 and not args.no_latency:
+            latency = latency_figures(E, synth, ctx, hp, dtype, args.tokens)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(hp, pcm_host[:max(1, min(args.cpu_windows, B))], args.cpu_tokens or args.tokens)
@@ -383,12 +397,12 @@ def main():
             "metric": baseline_metric(), "value": round(value, 1), "unit": "audio-sec/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.model} dims, batch={B} x 30 s windows per GPU, greedy, {args.tokens} tokens/window (EOT suppressed), "
-                                   f"procedural weights seed 1234, PCM resident in HBM", "model_dims": hp.as_list(),
+            "value_one_batch_in_flight": pipe.get("unpipelined_value") if pipe else round(value, 1),
+            "config": {"workload": workload_string(args, B, G if pipe and G > 1 else 0, MG, pipe), "model_dims": hp.as_list(),
                        "concurrent_sub_batches": S_saved, "pipeline": pipe,
                        "stage_ms_last_step": {"mel": round(tm.mel_ms, 2), "encode": round(tm.encode_ms, 2), "decode": round(tm.decode_ms, 2)},
                        "decode_steps": tm.decode_steps},
-            "roofline": roof, "roofline_mfma": mfma, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_mfma": mfma, "latency": latency, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
@@ -406,6 +420,138 @@ def main():
         for x in [es, full] + dss:
             x.close()
     ctx.close()
+
+
+def workload_string(args, B, lanes, merge, pipe):
+    """what the timed region ran, in one string (the driver keeps config.workload and drops the nested objects)"""
+    base = (f"{args.model} dims, steps of batch={B} x 30 s windows per GPU, greedy, {args.tokens} tokens/window (EOT suppressed), "
+            f"procedural weights seed 1234, every window a distinct synthetic recording, PCM resident in HBM")
+    if lanes:
+        strict = pipe.get("unpipelined_value")
+        return (base + f"; schedule LANES {lanes}x{merge}: {lanes * merge} steps ({lanes * merge * B} windows) in flight per GPU - per lane ONE front-end pass "
+                f"and ONE decode batch of {merge * B} rows, {lanes} decodes side by side on {pipe['decoder_cus']} CUs each; the same steps strictly one "
+                f"batch of {B} in flight: {strict} audio-s/s (value_one_batch_in_flight)")
+    if pipe:
+        return base + f"; schedule PIPELINE: 2 batches in flight (front end on {pipe['encoder_cus']} CUs beside the decode on {pipe['decoder_cus']})"
+    return base + "; one batch after the other"
+
+
+def decoder_step_bytes(hp, n_rows_windows=1):
+    """algorithmic HBM bytes of ONE single-token decoder step: every decoder weight once (16-bit) + the cross
+    K/V of every window once; the self-attention cache (a few hundred KB per window) is left out"""
+    d, L, V, T = hp.n_text_state, hp.n_text_layer, hp.n_vocab, hp.n_audio_ctx
+    weights = (L * 14 * d * d + V * d) * 2
+    xkv = n_rows_windows * L * 2 * T * d * 2
+    return weights + xkv
+
+
+def latency_figures(E, synth, ctx, hp, dtype, n_tokens):
+    """The small-batch figures (untimed for `value`): what the daemon's one-utterance path and BASELINE configs #2 / #5 see.
+    Each is the median of 3 runs after one warm-up, host wall clock around the blocking C-ABI calls."""
+    import statistics as stat
+    out = {}
+
+    def med(f, n=3):
+        f()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter(); f(); ts.append(1e3 * (time.perf_counter() - t0))
+        return stat.median(ts)
+    pcm1 = synth.synth_audio(777)[None]
+    # (1) large-v3 (the bench's model) at batch 1: greedy decode, ms per token against the step's byte bound
+    st = E.State(ctx, 1)
+    p = ctx.default_params(); p.force_len = n_tokens
+    st.mel(pcm1, None, E.OHW_MEL_ZERO_TAIL, want=False); st.encode(1)
+    dec_ms = med(lambda: st.greedy(1, p))
+    front_ms = med(lambda: (st.mel(pcm1, None, E.OHW_MEL_ZERO_TAIL, want=False), st.encode(1), st.fetch("mel", 1)))
+    per_tok = dec_ms / n_tokens
+    bound_ms = 1e3 * decoder_step_bytes(hp) / (PEAK_HBM_GBS * 1e9)
+    out["b1_large_v3_ms_per_token"] = {"value": round(per_tok, 4), "hbm_bound_ms": round(bound_ms, 4), "frac": round(bound_ms / per_tok, 4),
+                                       "window_ms": round(front_ms + dec_ms, 2), "front_end_ms": round(front_ms, 2), "tokens": n_tokens}
+    st.close()
+    # (2) BASELINE config #5: one 5 s chunk, beam = 5, 48 decoder steps (procedural weights never finish early), mel + encoder +
+    # cross K/V + beam search on one window (tools/streaming_latency.py drives the same through StreamingSession)
+    K, steps5 = 5, 48
+    st5 = E.State(ctx, K)
+    p5 = ctx.default_params(); p5.n_max = steps5
+    chunk = synth.synth_audio(778)[:80000][None]
+
+    def cfg5():
+        st5.mel(chunk, [80000], E.OHW_MEL_ZERO_TAIL, want=False); st5.encode(1); st5.beam_search(1, K, p5)
+    c5 = med(cfg5)
+    b5 = 1e3 * steps5 * decoder_step_bytes(hp) / (PEAK_HBM_GBS * 1e9)
+    out["cfg5_beam5_chunk_ms"] = {"value": round(c5, 2), "hbm_bound_ms_decode": round(b5, 2), "frac": round(b5 / c5, 4), "beam": K, "decoder_steps": steps5,
+                                  "chunk_s": 5.0}
+    st5.close()
+    # (3) BASELINE config #2: `small` dims, batch 1, one 30 s window, greedy, the same token count
+    hs = synth.PRESETS["small"]
+    cs = E.Context.synthetic(hs.as_list(), 1234, 0, dtype)
+    ss = E.State(cs, 1)
+    ps = cs.default_params(); ps.force_len = n_tokens
+
+    def cfg2():
+        ss.mel(pcm1, None, E.OHW_MEL_ZERO_TAIL, want=False); ss.encode(1); ss.greedy(1, ps)
+    c2 = med(cfg2)
+    enc_flop = 2.0 * (1500 * (3 * 80 * hs.n_audio_state) * 2 + 1500 * 3 * hs.n_audio_state ** 2) + hs.n_audio_layer * (
+        2.0 * 1500 * 12 * hs.n_audio_state ** 2 + 4.0 * 1500 * 1500 * hs.n_audio_state) + 2.0 * 1500 * 2 * hs.n_text_layer * hs.n_text_state ** 2
+    b2 = 1e3 * (enc_flop / (PEAK_MFMA_TFLOPS * 1e12) + n_tokens * decoder_step_bytes(hs) / (PEAK_HBM_GBS * 1e9))
+    out["cfg2_small_b1_ms_per_window"] = {"value": round(c2, 2), "bound_ms": round(b2, 3), "frac": round(b2 / c2, 4), "tokens": n_tokens}
+    ss.close(); cs.close()
+    return out
+
+
+def pool_bench(args, torch, E, synth):
+    """bench.py --pool: the single-process multi-GPU design behind the C ABI (openhush_amd/csrc/pool.cpp).  A step is still one
+    batch of --batch windows per GPU; the K timed steps are ONE ohw_pool_transcribe of a recording of gpus x batch x K windows
+    (host PCM in, token ids out: PCIe-inclusive, unlike the default mode), every window forced to --tokens tokens."""
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("--pool is ONE process: launch it plainly, not under torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    devices = [int(x) for x in args.pool_devices.split(",")] if args.pool_devices else list(range(args.gpus))
+    n_dev = len(devices)
+    hp = synth.PRESETS[args.model]
+    dtype = E.OHW_DTYPE_BF16 if args.dtype == "bf16" else E.OHW_DTYPE_F16
+    B = args.batch
+    t0 = time.perf_counter()
+    pool = E.EnginePool(None, "en", False, devices, dtype, B, synthetic=hp.as_list(), seed=1234)
+    load_s = time.perf_counter() - t0
+    pool.set_decode_policy(temperature_inc=0.0)
+    pool.set_force_len(args.tokens)
+    if args.phases > 1:
+        pool.set_schedule(E.OHW_SCHEDULE_LANES, args.phases, max(1, args.merge))
+    else:
+        pool.set_schedule(E.OHW_SCHEDULE_SEQUENTIAL if args.pipeline <= 0 else E.OHW_SCHEDULE_PIPELINE)
+
+    def recording(n_steps, first_id):
+        n_win = n_dev * B * n_steps
+        out = np.empty(n_win * synth.CHUNK_SAMPLES, np.float32)
+        for w in range(n_win):
+            out[w * synth.CHUNK_SAMPLES:(w + 1) * synth.CHUNK_SAMPLES] = synth.synth_audio(first_id + w)
+        return out
+    if args.warmup > 0:
+        pool.transcribe(E.AudioBuffer(recording(args.warmup, 0), 16000))
+    rec = recording(args.steps, 100000)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pool.transcribe(E.AudioBuffer(rec, 16000))
+    dt = time.perf_counter() - t0
+    lens = pool.last_window_tokens()
+    assert len(lens) == n_dev * B * args.steps and all(n == args.tokens for n in lens), "every window must decode exactly --tokens tokens"
+    value = 30.0 * len(lens) / dt
+    line = {
+        "metric": baseline_metric(), "value": round(value, 1), "unit": "audio-sec/sec", "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {"workload": f"--pool: ONE process, ohw_pool_transcribe over devices {devices} ({pool.broadcast_kind} weight broadcast"
+                               f"{': ' + pool.broadcast_note if pool.broadcast_note else ''}), {args.model} dims, one recording of {len(lens)} distinct 30 s windows = "
+                               f"{args.steps} steps of batch={B} per GPU dealt round-robin, greedy, {args.tokens} tokens/window (EOT suppressed), HOST PCM in "
+                               f"(PCIe-inclusive), engine schedule {'LANES %dx%d' % (args.phases, args.merge) if args.phases > 1 else 'sequential/pipeline'}",
+                   "model_dims": hp.as_list(), "pool_load_s": round(load_s, 2), "broadcast": pool.broadcast_kind},
+        "roofline": None, "cpu_baseline": None,
+    }
+    print(json.dumps(line), flush=True)
+    pool.close()
 
 
 def baseline_metric():

@@ -443,6 +443,10 @@ int ohw_engine_last_trace(ohw_engine* e, const int32_t** data, int* n);
  * what whisper.cpp's front end gives a recording handed over in one call - instead of treating each cut as its own call. */
 enum { OHW_WINDOW_FIXED = 0, OHW_WINDOW_SEEK = 1, OHW_WINDOW_FIXED_RECORDING_MEL = 2 };
 int ohw_engine_set_window_mode(ohw_engine* e, int mode);
+/* measurement knob (bench.py --pool; SURVEY.md 8d "decode length is pinned"): n_tokens > 0 makes every window decode exactly
+ * that many tokens with end-of-text suppressed (ohw_sample_params.force_len; use with temperature_inc = 0: a forced sequence
+ * fails whisper.cpp's acceptance test by construction); 0 (default) = the reference's behaviour.                         */
+int ohw_engine_set_force_len(ohw_engine* e, int n_tokens);
 /* How audio of more than max_batch windows is overlapped on the device (the reference transcribes one buffer at a time,
  * src/queue/worker.rs:100-160; results are identical under every schedule):
  *   SEQUENTIAL  one batch after the other;
@@ -478,6 +482,12 @@ ohw_ctx* ohw_engine_ctx(ohw_engine* e);
 typedef struct ohw_pool ohw_pool;
 int ohw_pool_create(const char* model_path, const char* language, int translate, const int* device_ids, int n_devices,
                     int dtype, int max_batch, ohw_pool** out);
+/* the same pool around procedural weights made on device_ids[0] (ohw_ctx_create_synthetic) instead of a file read: what
+ * bench.py --pool and the tests use where no model file exists */
+int ohw_pool_create_synthetic(const ohw_hparams* hp, uint32_t seed, const char* language, int translate, const int* device_ids,
+                              int n_devices, int dtype, int max_batch, ohw_pool** out);
+int ohw_pool_set_force_len(ohw_pool* p, int n_tokens);                     /* ohw_engine_set_force_len on every engine */
+int ohw_pool_set_schedule(ohw_pool* p, int schedule, int lanes, int merge); /* ohw_engine_set_schedule on every engine */
 int ohw_pool_transcribe(ohw_pool* p, const float* samples, int64_t n, uint32_t sample_rate, char* text_buf, size_t text_cap,
                         char* language_out, uint64_t* duration_ms, ohw_audio_info* info);
 int ohw_pool_last_text(ohw_pool* p, const char** text, size_t* len);

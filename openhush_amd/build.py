@@ -17,13 +17,17 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # OHW_BUILD_VARIANT=trace builds libohw_trace.so with -DOHW_TRACE (in-kernel timestamps for tools/dec_trace.py);
-# the product library never carries that code
+# the product library never carries that code.  OHW_BUILD_VARIANT=asan builds libohw_asan.so with AddressSanitizer and
+# UBSan on the HOST code only (GPU sanitizers are not available on the pool): tools/asan_host.sh runs the CPU suite on it.
 VARIANT = os.environ.get("OHW_BUILD_VARIANT", "")
 OUT = os.path.join(HERE, f"libohw_{VARIANT}.so" if VARIANT else "libohw.so")
 BUILD = os.path.join(CSRC, f"_build_{VARIANT}" if VARIANT else "_build")
 SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "weights.hip", "mel.hip", "misc.hip", "decode.hip", "model.hip", "engine.hip", "host_engine.cpp", "pool.cpp", "dsp.cpp", "vad.cpp", "resample.hip", "tracker.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=fast-honor-pragmas",
-         "-fno-gpu-rdc"] + (["-DOHW_TRACE"] + os.environ.get("OHW_EXP_FLAGS", "").split() if VARIANT == "trace" else []) + ["-x", "hip"]
+         "-fno-gpu-rdc"] + (["-DOHW_TRACE"] + os.environ.get("OHW_EXP_FLAGS", "").split() if VARIANT == "trace" else []) + (
+             ["-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined", "-Xarch_host", "-fno-omit-frame-pointer", "-g"]
+             if VARIANT == "asan" else []) + ["-x", "hip"]
+LINK_EXTRA = ["-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined"] if VARIANT == "asan" else []
 
 
 def _hipcc() -> str:
@@ -71,7 +75,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     want = hashlib.sha256("\n".join(objs).encode()).hexdigest()
     have = open(stamp).read() if os.path.exists(stamp) else ""
     if force or have != want or not os.path.exists(OUT):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + LINK_EXTRA + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -182,6 +182,7 @@ void engine_transcribe_core(ohw_engine* e, const float* samples, int64_t n, std:
     // reference :251-257 passes !translate to whisper-rs on the claim that the binding is inverted;
     // the resulting behaviour the reference documents is: config translate=true -> translate task
     sp.translate = e->translate ? 1 : 0;
+    if (e->force_len > 0) { sp.force_len = std::min(e->force_len, sp.n_max); sp.n_max = sp.force_len; }      // bench: fixed decode length
     const ohw_special_tokens& tk = e->ctx->tok;
     if (sp.lang_id >= tk.n_langs) throw Error(OHW_E_TRANSCRIBE, "language is not supported by this model");
 
@@ -906,6 +907,12 @@ int ohw_engine_set_schedule(ohw_engine* e, int schedule, int lanes, int merge) {
   e->schedule = schedule;
   if (lanes > 0) e->lanes = lanes;
   if (merge > 0) e->merge = std::min(merge, std::max(1, 256 / e->max_batch));
+  return OHW_OK;
+}
+
+int ohw_engine_set_force_len(ohw_engine* e, int n_tokens) {
+  if (!e || n_tokens < 0) return OHW_E_INVALID_ARG;
+  e->force_len = n_tokens;
   return OHW_OK;
 }
 

@@ -13,6 +13,7 @@ struct ohw_engine {
   bool translate = false;
   int max_batch = 1;
   int window_mode = OHW_WINDOW_FIXED;
+  int force_len = 0;                     // measurement knob (ohw_engine_set_force_len): every window decodes exactly this many tokens
   std::vector<int32_t> last_tokens;
   std::string last_text;
   std::vector<ohw_window_quality> last_quality;

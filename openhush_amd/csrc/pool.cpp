@@ -192,57 +192,80 @@ std::string broadcast_weights(const std::vector<ohw_ctx*>& ctxs, const std::vect
 
 extern "C" {
 
+}  // extern "C"
+
+namespace {
+// the pool around a first context made by `make_first` on device_ids[0] (a model file read, or procedural weights)
+template <typename MakeFirst>
+ohw_pool* pool_build(const char* language, int translate, const int* device_ids, int n_devices, int dtype, int max_batch, MakeFirst&& make_first) {
+  if (!device_ids || n_devices < 1 || n_devices > 64) throw Error(OHW_E_INVALID_ARG, "pool: device_ids / n_devices");
+  const std::string lang = language ? language : "auto";
+  if (lang != "auto" && ohw_lang_code_to_id(lang.c_str()) < 0) throw Error(OHW_E_LOAD_FAILED, "unknown language code '" + lang + "'");
+  std::unique_ptr<ohw_pool> p(new ohw_pool());
+  p->language = lang;
+  p->devices.assign(device_ids, device_ids + n_devices);
+  std::vector<ohw_ctx*> ctxs((size_t)n_devices, nullptr);
+  auto cleanup = [&] {
+    for (ohw_engine* e : p->engines) ohw_engine_free(e);
+    p->engines.clear();
+    for (ohw_ctx* c : ctxs) if (c) ohw_ctx_free(c);
+  };
+  try {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess) n_dev = 0;
+    for (int i = 0; i < n_devices; ++i)            // before the 3 GB file read: a bad id names itself
+      if (device_ids[i] < 0 || device_ids[i] >= n_dev)
+        throw Error(OHW_E_NO_GPU, "pool: device " + std::to_string(device_ids[i]) + " (entry " + std::to_string(i) + " of the device list) does not exist: " +
+                                      std::to_string(n_dev) + " device(s) visible");
+    int rc = make_first(&ctxs[0]);                  // the one file read
+    if (rc != OHW_OK) throw Error(rc == OHW_E_NO_GPU || rc == OHW_E_OOM ? rc : OHW_E_LOAD_FAILED, "pool: device " + std::to_string(device_ids[0]) + ": Failed to load model: " + g_last_error);
+    ohw_hparams hp;
+    (void)ohw_ctx_info(ctxs[0], &hp, nullptr);
+    dtype = ohw_ctx_dtype(ctxs[0]);                       // what OHW_DTYPE_AUTO resolved to
+    for (int i = 1; i < n_devices; ++i) {
+      rc = ohw_ctx_create_shell(&hp, device_ids[i], dtype, &ctxs[(size_t)i]);
+      if (rc != OHW_OK) throw Error(rc, "pool: device " + std::to_string(device_ids[i]) + " (entry " + std::to_string(i) + " of the device list): " + g_last_error);
+    }
+    try {
+      p->broadcast = broadcast_weights(ctxs, p->devices, &p->broadcast_note);
+    } catch (const Error& e) {
+      throw Error(e.code, std::string("pool: weight broadcast: ") + e.what());
+    }
+    for (int i = 0; i < n_devices; ++i) {
+      ohw_engine* e = engine_wrap_ctx(ctxs[(size_t)i], lang, translate != 0, max_batch, device_ids[i]);
+      ctxs[(size_t)i] = nullptr;                 // owned by the engine now
+      p->engines.push_back(e);
+    }
+  } catch (...) {
+    cleanup();
+    throw;
+  }
+  return p.release();
+}
+}  // namespace
+
+extern "C" {
+
 int ohw_pool_create(const char* model_path, const char* language, int translate, const int* device_ids, int n_devices, int dtype,
                     int max_batch, ohw_pool** out) {
   return guard([&] {
     if (!out) throw Error(OHW_E_INVALID_ARG, "out is null");
     *out = nullptr;
-    if (!device_ids || n_devices < 1 || n_devices > 64) throw Error(OHW_E_INVALID_ARG, "pool: device_ids / n_devices");
     struct stat sb;
     if (!model_path || stat(model_path, &sb) != 0)
       throw Error(OHW_E_MODEL_NOT_FOUND, std::string("Model not found at ") + (model_path ? model_path : "(null)"));
-    const std::string lang = language ? language : "auto";
-    if (lang != "auto" && ohw_lang_code_to_id(lang.c_str()) < 0) throw Error(OHW_E_LOAD_FAILED, "unknown language code '" + lang + "'");
-    std::unique_ptr<ohw_pool> p(new ohw_pool());
-    p->language = lang;
-    p->devices.assign(device_ids, device_ids + n_devices);
-    std::vector<ohw_ctx*> ctxs((size_t)n_devices, nullptr);
-    auto cleanup = [&] {
-      for (ohw_engine* e : p->engines) ohw_engine_free(e);
-      p->engines.clear();
-      for (ohw_ctx* c : ctxs) if (c) ohw_ctx_free(c);
-    };
-    try {
-      int n_dev = 0;
-      if (hipGetDeviceCount(&n_dev) != hipSuccess) n_dev = 0;
-      for (int i = 0; i < n_devices; ++i)            // before the 3 GB file read: a bad id names itself
-        if (device_ids[i] < 0 || device_ids[i] >= n_dev)
-          throw Error(OHW_E_NO_GPU, "pool: device " + std::to_string(device_ids[i]) + " (entry " + std::to_string(i) + " of the device list) does not exist: " +
-                                        std::to_string(n_dev) + " device(s) visible");
-      int rc = ohw_ctx_create(model_path, device_ids[0], dtype, &ctxs[0]);      // the one file read
-      if (rc != OHW_OK) throw Error(rc == OHW_E_NO_GPU || rc == OHW_E_OOM ? rc : OHW_E_LOAD_FAILED, "pool: device " + std::to_string(device_ids[0]) + ": Failed to load model: " + g_last_error);
-      ohw_hparams hp;
-      (void)ohw_ctx_info(ctxs[0], &hp, nullptr);
-      dtype = ohw_ctx_dtype(ctxs[0]);                       // what OHW_DTYPE_AUTO resolved to
-      for (int i = 1; i < n_devices; ++i) {
-        rc = ohw_ctx_create_shell(&hp, device_ids[i], dtype, &ctxs[(size_t)i]);
-        if (rc != OHW_OK) throw Error(rc, "pool: device " + std::to_string(device_ids[i]) + " (entry " + std::to_string(i) + " of the device list): " + g_last_error);
-      }
-      try {
-        p->broadcast = broadcast_weights(ctxs, p->devices, &p->broadcast_note);
-      } catch (const Error& e) {
-        throw Error(e.code, std::string("pool: weight broadcast: ") + e.what());
-      }
-      for (int i = 0; i < n_devices; ++i) {
-        ohw_engine* e = engine_wrap_ctx(ctxs[(size_t)i], lang, translate != 0, max_batch, device_ids[i]);
-        ctxs[(size_t)i] = nullptr;                 // owned by the engine now
-        p->engines.push_back(e);
-      }
-    } catch (...) {
-      cleanup();
-      throw;
-    }
-    *out = p.release();
+    *out = pool_build(language, translate, device_ids, n_devices, dtype, max_batch,
+                      [&](ohw_ctx** c) { return ohw_ctx_create(model_path, device_ids[0], dtype, c); });
+  });
+}
+
+int ohw_pool_create_synthetic(const ohw_hparams* hp, uint32_t seed, const char* language, int translate, const int* device_ids, int n_devices,
+                              int dtype, int max_batch, ohw_pool** out) {
+  return guard([&] {
+    if (!out || !hp) throw Error(OHW_E_INVALID_ARG, "out / hp is null");
+    *out = nullptr;
+    *out = pool_build(language, translate, device_ids, n_devices, dtype == OHW_DTYPE_AUTO ? OHW_DTYPE_BF16 : dtype, max_batch,
+                      [&](ohw_ctx** c) { return ohw_ctx_create_synthetic(hp, seed, device_ids[0], dtype == OHW_DTYPE_AUTO ? OHW_DTYPE_BF16 : dtype, c); });
   });
 }
 
@@ -265,6 +288,22 @@ int ohw_pool_set_window_mode(ohw_pool* p, int mode) {
   return OHW_OK;
 }
 const char* ohw_pool_broadcast_note(const ohw_pool* p) { return p ? p->broadcast_note.c_str() : ""; }
+int ohw_pool_set_force_len(ohw_pool* p, int n_tokens) {
+  if (!p) return OHW_E_INVALID_ARG;
+  for (ohw_engine* e : p->engines) {
+    const int rc = ohw_engine_set_force_len(e, n_tokens);
+    if (rc != OHW_OK) return rc;
+  }
+  return OHW_OK;
+}
+int ohw_pool_set_schedule(ohw_pool* p, int schedule, int lanes, int merge) {
+  if (!p) return OHW_E_INVALID_ARG;
+  for (ohw_engine* e : p->engines) {
+    const int rc = ohw_engine_set_schedule(e, schedule, lanes, merge);
+    if (rc != OHW_OK) return rc;
+  }
+  return OHW_OK;
+}
 
 int ohw_pool_set_decode_policy(ohw_pool* p, const ohw_decode_policy* q) {
   if (!p || !q) return OHW_E_INVALID_ARG;

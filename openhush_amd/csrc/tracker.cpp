@@ -9,8 +9,8 @@
 //   ohw_chunk_scheduler_*  <- the chunk-timer arm of the daemon loop (reference src/daemon.rs:1958-2011): on a tick the
 //                             audio since the last tick becomes a job registered with the tracker; a job the tracker refuses
 //                             is skipped but the position still advances; a chunk that is too short moves nothing
-// The Python mirrors (openhush_amd/tracker.py, streaming.py) carry the reference's unit tests; tests/test_tracker_c.py runs
-// the same cases through this file.
+// The reference's unit tests (src/queue/mod.rs:318-469) are restated in tests/test_tracker.py, which runs every case through the
+// Python mirror (openhush_amd/tracker.py) AND through this file (NativeTranscriptionTracker), plus a randomised differential test.
 #include <cstring>
 #include <map>
 #include <new>

@@ -142,7 +142,7 @@ EXPORTS = [
     "ohw_vad_run",
     "ohw_pool_create", "ohw_pool_transcribe", "ohw_pool_last_text", "ohw_pool_last_tokens", "ohw_pool_last_quality",
     "ohw_dbg_counter", "ohw_dsp_denoise", "ohw_denoise_passthrough_engine", "ohw_preprocess_audio_ex", "ohw_pool_set_window_mode",
-    "ohw_pool_broadcast_note",
+    "ohw_pool_broadcast_note", "ohw_pool_create_synthetic", "ohw_pool_set_force_len", "ohw_pool_set_schedule", "ohw_engine_set_force_len",
     "ohw_pool_set_decode_policy", "ohw_pool_n_devices", "ohw_pool_broadcast_kind", "ohw_pool_engine", "ohw_pool_free",
 ]
 
@@ -212,6 +212,10 @@ def lib():
         L.ohw_denoise_passthrough_engine.restype = None
         L.ohw_preprocess_audio_ex.argtypes = [fp, C.c_int64, C.c_uint32, C.POINTER(PreprocessConfig), C.c_int, C.c_float, C.POINTER(DenoiseEngineC)]
         L.ohw_pool_set_window_mode.argtypes = [vp, C.c_int]
+        L.ohw_pool_create_synthetic.argtypes = [C.POINTER(HParams), C.c_uint32, C.c_char_p, C.c_int, ip, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        L.ohw_pool_set_force_len.argtypes = [vp, C.c_int]
+        L.ohw_pool_set_schedule.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+        L.ohw_engine_set_force_len.argtypes = [vp, C.c_int]
         L.ohw_pool_broadcast_note.argtypes = [vp]
         L.ohw_pool_broadcast_note.restype = C.c_char_p
         L.ohw_dsp_rms_db.argtypes = [fp, C.c_int64]
@@ -1109,14 +1113,25 @@ class EnginePool:
     """ohw_pool: one engine per device of one node behind the C ABI (the reference's `[gpu] devices` intent,
     src/config.rs:921-929).  transcribe() has WhisperEngine.transcribe's contract."""
 
-    def __init__(self, model_path: str, language: str = "auto", translate: bool = False, devices: Sequence[int] = (0,),
-                 dtype: int = OHW_DTYPE_BF16, max_batch: int = 1):
+    def __init__(self, model_path: Optional[str], language: str = "auto", translate: bool = False, devices: Sequence[int] = (0,),
+                 dtype: int = OHW_DTYPE_BF16, max_batch: int = 1, synthetic: Optional[Sequence[int]] = None, seed: int = 1234):
+        """model_path: a ggml file; or synthetic = hparams list: procedural weights made on devices[0] (no file)"""
         ids = np.asarray(list(devices), dtype=np.int32)
         h = C.c_void_p()
-        rc = lib().ohw_pool_create(str(model_path).encode(), language.encode(), int(translate), _ip(ids), len(ids), dtype, max_batch, C.byref(h))
+        if synthetic is not None:
+            hp = HParams(*[int(x) for x in synthetic])
+            rc = lib().ohw_pool_create_synthetic(C.byref(hp), seed, language.encode(), int(translate), _ip(ids), len(ids), dtype, max_batch, C.byref(h))
+        else:
+            rc = lib().ohw_pool_create(str(model_path).encode(), language.encode(), int(translate), _ip(ids), len(ids), dtype, max_batch, C.byref(h))
         if rc != 0:
             _raise(rc)
         self.h = h
+
+    def set_force_len(self, n_tokens: int):
+        _check(lib().ohw_pool_set_force_len(self.h, n_tokens))
+
+    def set_schedule(self, schedule: int, lanes: int = 0, merge: int = 0):
+        _check(lib().ohw_pool_set_schedule(self.h, schedule, lanes, merge))
 
     @property
     def n_devices(self) -> int:
