@@ -364,6 +364,12 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* p, int n_windows, in
  * Set on ohw_engine_state(e) it holds for every state ohw_engine_transcribe decodes on (the schedules' lane states too). */
 int ohw_state_set_logit_bias(ohw_state* st, const float* bias, int n);
 
+/* the persistent small-batch decoder step (default on; OHW_DEC_PERSIST=0 turns it off for new states): single-token steps
+ * of at most 16 rows - one utterance, the K rows of a beam search - run their 32 layers as ONE launch whose workgroups hand
+ * activations to each other (openhush_amd/csrc/decode_persist.hip) instead of 8 launches per layer.  Never used under
+ * ohw_state_set_batch_invariant.  Results are deterministic and a row's result does not depend on the other rows.        */
+int ohw_state_set_persistent(ohw_state* st, int on);
+
 /* batch-invariant decoding (default off): the decoder picks some kernel variants from the number of rows in flight - up to
  * 24 rows the keys of a cross-attention (row, head) are cut over several workgroups, and the prompt pass shares one K/V
  * stream among a window's rows only when there are enough windows - and a different variant sums the softmax in a
@@ -530,7 +536,8 @@ int ohw_dbg_attention(int dtype, const void* qkv, void* out, int batch, int T, i
 int ohw_dbg_sample(ohw_state* st, const ohw_sample_params* p, const float* logits, const int32_t* history, int hist_stride,
                    const int32_t* n_hist, int batch, int32_t* tokens_out, float* logprobs_out, float* no_speech_out);
 /* counters of a state's graph caches: "step_captures" / "beam_captures" (graphs / graph pairs captured so far),
- * "step_graphs" / "beam_graphs" (entries held now); OHW_E_INVALID_ARG for another name.  A second ohw_greedy /
+ * "step_graphs" / "beam_graphs" (entries held now), "persist_launches" (persistent decoder steps launched or captured);
+ * OHW_E_INVALID_ARG for another name.  A second ohw_greedy /
  * ohw_beam_search with the same batch, parameters and stream must add no capture (tests/test_gpu_beam.py).        */
 int ohw_dbg_counter(const ohw_state* st, const char* name);
 

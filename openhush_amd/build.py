@@ -22,7 +22,7 @@ CSRC = os.path.join(HERE, "csrc")
 VARIANT = os.environ.get("OHW_BUILD_VARIANT", "")
 OUT = os.path.join(HERE, f"libohw_{VARIANT}.so" if VARIANT else "libohw.so")
 BUILD = os.path.join(CSRC, f"_build_{VARIANT}" if VARIANT else "_build")
-SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "weights.hip", "mel.hip", "misc.hip", "decode.hip", "model.hip", "engine.hip", "host_engine.cpp", "pool.cpp", "dsp.cpp", "vad.cpp", "resample.hip", "tracker.cpp"]
+SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "weights.hip", "mel.hip", "misc.hip", "decode.hip", "decode_persist.hip", "model.hip", "engine.hip", "host_engine.cpp", "pool.cpp", "dsp.cpp", "vad.cpp", "resample.hip", "tracker.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=fast-honor-pragmas",
          "-fno-gpu-rdc"] + (["-DOHW_TRACE"] + os.environ.get("OHW_EXP_FLAGS", "").split() if VARIANT == "trace" else []) + (
              ["-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined", "-Xarch_host", "-fno-omit-frame-pointer", "-g"]

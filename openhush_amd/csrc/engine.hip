@@ -129,8 +129,14 @@ struct ohw_state {
   // one entry = the PAIR of graphs of a (windows, beam size, sampler parameters, CU budget, cross-attention variant) key: the
   // odd and the even iteration (the token-history and kv_slot double buffers alternate); made, looked up and evicted together,
   // so a call never holds an exec of an entry it then evicts
-  struct BeamGraph { hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t exec[2] = {nullptr, nullptr}; int windows = 0, K = 0, cus = 0; bool invariant = false; SamplerParams spar; };
+  struct BeamGraph { hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t exec[2] = {nullptr, nullptr}; int windows = 0, K = 0, cus = 0; bool invariant = false, persist = false; SamplerParams spar; };
   std::vector<BeamGraph> beam_graphs;
+  // the persistent small-batch decoder step (decode_persist.hip): per-layer pointer table, granule arena, epoch / abort words
+  DevBuf ps_layers, ps_gran, ps_words;
+  PersistParams ps_layout{};         // region offsets of the arena
+  bool persist = true;               // OHW_DEC_PERSIST / ohw_state_set_persistent
+  int persist_launches = 0;
+  int n_cu = 0;
   int step_captures = 0;
   int beam_captures = 0;            // graph pairs captured so far (ohw_dbg_counter: a second call with the same key adds none)
   DevBuf tok_lp, nosp_prob;        // per-token log-probabilities [B][max_tokens + 1], no-speech probability [B]
@@ -146,7 +152,7 @@ struct ohw_state {
   double prof_work = 0.0;
   // hipGraph of one greedy iteration {feed sampled token, single-token decoder step, sampler}
   // captured greedy iterations, one per (batch, sampler parameters, CU budget of the stream) seen; a handful at most
-  struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int batch = 0; int cus = 0; bool invariant = false; SamplerParams spar{}; };
+  struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int batch = 0; int cus = 0; bool invariant = false, persist = false; SamplerParams spar{}; };
   bool batch_invariant = false;      // cross-attention variant picked from n_new alone (state_set_batch_invariant)
   std::vector<StepGraph> step_graphs;
   bool graphs_enabled = true;
@@ -226,6 +232,8 @@ void state_alloc(ohw_state* st) {
   // stalls inside a replay (tools/lane_gap_analysis.py) - and a lane's first call no longer waits, at its capture, for the
   // other lanes to leave the library
   st->graph_max_batch = env_int("OHW_GRAPH_MAX_BATCH", 32, 1, 1 << 20);
+  st->persist = env_int("OHW_DEC_PERSIST", 1, 0, 1) != 0;
+  (void)hipDeviceGetAttribute(&st->n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
   st->postnorm = env_int("OHW_DEC_POSTNORM", 0, 0, 1) != 0 && dec_ksplit_long() == 1 && dec_ksplit_short() == 1 && dt % 32 == 0;
   st->dx16.alloc(m_tiles * dt * 2, true);
   st->xstat.alloc((size_t)st->m_max * (dt / 16) * 2 * 4, true);
@@ -342,6 +350,57 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
   if (M > st->m_max) throw Error(OHW_E_INVALID_ARG, "decode: batch * n_new exceeds the state's capacity (8 tokens per window per call)");
   const int32_t* n_past = st->n_past.as<int32_t>();
   const bool pn = st->postnorm;
+  // ---- at most 16 single-token rows: the 32 layers in ONE persistent launch (decode_persist.hip) instead of 8 launches per
+  // layer.  Not under ohw_state_set_batch_invariant (a window's bits must then not depend on which path its batch takes), not
+  // while a kernel class is being profiled, not on the experimental post-norm / split-K paths.
+  if (st->persist && n_new == 1 && M <= 16 && kv_group <= 5 && M % kv_group == 0 && !st->batch_invariant && !pn && st->prof_class == 0 &&
+      st->ksplit_long == 1 && st->ksplit_short == 1 && d % 64 == 0 && d <= 1280 && H * 64 == d) {
+    const int grid = std::max(1, std::min(st->stream_cus > 0 ? st->stream_cus : st->n_cu, 256));
+    PersistParams q = st->ps_layout;
+    if (!st->ps_gran.p) {
+      q = PersistParams{};
+      q.d = d; q.H = H;
+      const int64_t n_gran = persist_layout(&q);
+      st->ps_gran.alloc((size_t)n_gran * 8, true);
+      st->ps_words.alloc(64, true);
+      const unsigned one = 1;
+      HIP_CHECK(hipMemcpy(st->ps_words.p, &one, 4, hipMemcpyHostToDevice));
+      std::vector<PersistLayer> lw((size_t)L);
+      for (int l = 0; l < L; ++l) {
+        const DecLayerW& w = c->dec[l];
+        lw[(size_t)l] = PersistLayer{w.wqkv.p, w.wo.p, w.wxq.p, w.wxo.p, w.w1.p, w.w2.p, w.bqkv.as<float>(), w.bo.as<float>(), w.bxq.as<float>(),
+                                     w.bxo.as<float>(), w.b1.as<float>(), w.b2.as<float>()};
+      }
+      st->ps_layers.alloc(lw.size() * sizeof(PersistLayer));
+      HIP_CHECK(hipMemcpy(st->ps_layers.p, lw.data(), lw.size() * sizeof(PersistLayer), hipMemcpyHostToDevice));
+      st->ps_layout = q;
+    }
+    launch_embed<T>(c->emb.p, c->dec_pos.as<float>(), tok_src ? tok_src : st->step_tok.as<int32_t>(), n_past, st->dx.as<float>(), nullptr, nullptr, M, 1, d, s);
+    const int Wn = M / kv_group;
+    q.layers = st->ps_layers.as<PersistLayer>(); q.L = L; q.M = M; q.group = kv_group; q.d = d; q.H = H; q.n_ctx = C; q.t_len = Tn;
+    q.S = std::max(1, std::min(16, grid / std::max(1, Wn * H)));
+    const int kb_mlp = 4 * d / 32;
+    int ns = std::max(1, std::min(4, (grid + d / 16 - 1) / (d / 16)));
+    while (ns < 4 && (kb_mlp + ns - 1) / ns + 1 > 56) ++ns;
+    while (ns > 1 && kb_mlp / ns < 1) --ns;
+    q.nsplit = ns;
+    q.n_past = n_past; q.kv_slot = kv_slot;
+    q.done = kv_group > 1 ? win_done : (st->skip_done ? st->done.as<int32_t>() : nullptr);
+    q.x_in = st->dx.as<float>(); q.x_out = st->dx.as<float>();
+    q.self_kv = st->self_kv.p; q.kv_layer = (int64_t)st->max_batch * H * C * 64; q.kv_row = (int64_t)H * C * 64;
+    if ((int64_t)st->max_batch * q.kv_row * 2 >= ((int64_t)1 << 32)) throw Error(OHW_E_INVALID_ARG, "persistent step: a layer's K cache exceeds 4 GiB");
+    q.xkv = st->xkv.p; q.xkv_slab = (int64_t)Wn * H * Tn * 64;
+    q.g = st->ps_gran.as<unsigned long long>();
+    q.epoch = st->ps_words.as<unsigned>(); q.abort_word = st->ps_words.as<unsigned>() + 8;
+    launch_persist_step<T>(q, grid, s);
+    ++st->persist_launches;
+    launch_layernorm<T>(st->dx.as<float>(), c->dec_ln.g.as<float>(), c->dec_ln.b.as<float>(), st->dy.p, M, d, s, true);
+    DecGemmParams lp{};
+    lp.x = st->dy.p; lp.w = c->emb.p; lp.bias = nullptr; lp.out = st->logits.p; lp.cu_budget = st->stream_cus;
+    lp.M = M; lp.N = hp.n_vocab; lp.K = d; lp.n_new = 1; lp.ld_out = st->logits_ld; lp.n_past = n_past; lp.d_model = d; lp.n_head = H; lp.n_ctx = C;
+    launch_dec_gemm<T>(lp, DEPI_LOGITS, s);
+    return;
+  }
   launch_embed<T>(c->emb.p, c->dec_pos.as<float>(), tok_src ? tok_src : st->step_tok.as<int32_t>(), n_past, st->dx.as<float>(),
                   pn ? st->dx16.p : nullptr, pn ? st->xstat.as<float>() : nullptr, M, n_new, d, s);
   const int64_t kv_layer = (int64_t)st->max_batch * H * C * 64;      // elements per K (or V) cache of one layer
@@ -403,6 +462,19 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
   launch_layernorm<T>(st->dx.as<float>(), c->dec_ln.g.as<float>(), c->dec_ln.b.as<float>(), st->dy.p, M, d, s, true);
   DevBuf none;
   gemm(st->dy.p, nullptr, c->emb, none, st->logits.p, hp.n_vocab, d, DEPI_LOGITS, st->logits_ld);
+}
+
+// after a stream synchronisation: did a workgroup of a persistent decoder step give up waiting (decode_persist.hip)?  Loud.
+void persist_check(ohw_state* st) {
+  if (!st->ps_words.p || st->persist_launches == 0) return;
+  unsigned w = 0;
+  HIP_CHECK(hipMemcpy(&w, st->ps_words.as<unsigned>() + 8, 4, hipMemcpyDeviceToHost));
+  if (w != 0) {
+    const unsigned zero = 0;
+    (void)hipMemcpy(st->ps_words.as<unsigned>() + 8, &zero, 4, hipMemcpyHostToDevice);
+    throw Error(OHW_E_TRANSCRIBE, "persistent decoder step: a workgroup gave up waiting in layer " + std::to_string((w - 1) / 10) + ", phase " +
+                                      std::to_string((w - 1) % 10) + " (are all workgroups resident? OHW_DEC_PERSIST=0 selects the launch-per-kernel path)");
+  }
 }
 
 void fill_sampler(const ohw_state* st, const ohw_sample_params* sp, int B, SamplerParams* p) {
@@ -793,6 +865,7 @@ int ohw_decode_active(ohw_state* st, const int32_t* tokens, int n_new, const int
       }
     }
     HIP_CHECK(hipStreamSynchronize(s));   // also keeps `skip` alive until its copy has run
+    persist_check(st);
   });
 }
 
@@ -858,7 +931,7 @@ int ohw_greedy_ex(ohw_state* st, const ohw_sample_params* sp, int batch, int max
       hipGraphExec_t step_exec = nullptr;
       if (use_graph) {
         for (auto& g : st->step_graphs)
-          if (g.batch == batch && g.cus == st->stream_cus && g.invariant == st->batch_invariant && std::memcmp(&g.spar, &spar, sizeof spar) == 0) step_exec = g.exec;
+          if (g.batch == batch && g.cus == st->stream_cus && g.invariant == st->batch_invariant && g.persist == st->persist && std::memcmp(&g.spar, &spar, sizeof spar) == 0) step_exec = g.exec;
       }
       if (use_graph && !step_exec) {
         if (st->step_graphs.size() >= 8) {     // bounded: drop the oldest capture
@@ -893,7 +966,7 @@ int ohw_greedy_ex(ohw_state* st, const ohw_sample_params* sp, int batch, int max
         HIP_CHECK(hipStreamEndCapture(cap, &ng.graph));
         hipError_t ie = hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0);
         if (ie != hipSuccess) { (void)hipGraphDestroy(ng.graph); HIP_CHECK(ie); }
-        ng.batch = batch; ng.cus = st->stream_cus; ng.invariant = st->batch_invariant; ng.spar = spar;
+        ng.batch = batch; ng.cus = st->stream_cus; ng.invariant = st->batch_invariant; ng.persist = st->persist; ng.spar = spar;
         st->step_graphs.push_back(ng);
         ++st->step_captures;
         step_exec = ng.exec;
@@ -928,6 +1001,7 @@ int ohw_greedy_ex(ohw_state* st, const ohw_sample_params* sp, int batch, int max
       HIP_CHECK(hipMemcpyAsync(lps.data(), st->tok_lp.p, lps.size() * 4, hipMemcpyDeviceToHost, s));
     }
     HIP_CHECK(hipStreamSynchronize(s));
+    persist_check(st);
     for (int b = 0; b < batch; ++b) {
       const int n = std::min(ncur[(size_t)b], max_tokens);
       n_tokens_out[b] = n;
@@ -1013,7 +1087,7 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* sp, int n_windows, i
       hipGraphExec_t exec[2] = {nullptr, nullptr};
       if (use_graph) {
         for (auto& g : st->beam_graphs)
-          if (g.windows == W && g.K == K && g.cus == st->stream_cus && g.invariant == st->batch_invariant && std::memcmp(&g.spar, &base, sizeof base) == 0) {
+          if (g.windows == W && g.K == K && g.cus == st->stream_cus && g.invariant == st->batch_invariant && g.persist == st->persist && std::memcmp(&g.spar, &base, sizeof base) == 0) {
             exec[0] = g.exec[0]; exec[1] = g.exec[1];
           }
       }
@@ -1061,7 +1135,7 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* sp, int n_windows, i
           drop();
           throw;
         }
-        ng.windows = W; ng.K = K; ng.cus = st->stream_cus; ng.invariant = st->batch_invariant;
+        ng.windows = W; ng.K = K; ng.cus = st->stream_cus; ng.invariant = st->batch_invariant; ng.persist = st->persist;
         std::memcpy(&ng.spar, &base, sizeof base);
         st->beam_graphs.push_back(ng);
         ++st->beam_captures;
@@ -1099,6 +1173,7 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* sp, int n_windows, i
     HIP_CHECK(hipMemcpyAsync(live_sum.data(), st->bm_sum.p, (size_t)R * 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(ncur.data(), st->bm_ncur.p, (size_t)W * 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
+    persist_check(st);
     for (int w = 0; w < W; ++w) {
       struct Cand { const int32_t* t; int n; float sum; };
       std::vector<Cand> cands;
@@ -1137,7 +1212,14 @@ int ohw_dbg_counter(const ohw_state* st, const char* name) {
   if (n == "beam_graphs") return (int)st->beam_graphs.size();
   if (n == "step_captures") return st->step_captures;
   if (n == "step_graphs") return (int)st->step_graphs.size();
+  if (n == "persist_launches") return st->persist_launches;
   return OHW_E_INVALID_ARG;
+}
+
+int ohw_state_set_persistent(ohw_state* st, int on) {
+  if (!st) return OHW_E_INVALID_ARG;
+  st->persist = on != 0;
+  return OHW_OK;
 }
 
 int ohw_state_set_batch_invariant(ohw_state* st, int on) {

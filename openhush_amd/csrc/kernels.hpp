@@ -105,6 +105,32 @@ template <typename T> void launch_cross_attn(const void* q, const void* xk, cons
                                              int kv_group = 1 /* beam search: consecutive rows that share one window's K/V */,
                                              bool batch_invariant = false /* pick the variant from n_new alone, never from M */);
 
+// ---- the 32 decoder layers of a single-token step in ONE persistent launch, at most 16 rows (decode_persist.hip) ----------
+struct PersistLayer {
+  const void *wqkv, *wo, *wxq, *wxo, *w1, *w2;       // fragment tiles T [N/16][K/32][64][8]
+  const float *bqkv, *bo, *bxq, *bxo, *b1, *b2;
+};
+struct PersistParams {
+  const PersistLayer* layers;     // device [L]
+  int32_t L, M, group, d, H, n_ctx, t_len, S, nsplit;   // rows, rows per window, d_model, heads, positions, encoder positions, cross key slices, mlp.2 K slices
+  const int32_t* n_past;     // [M]
+  const int32_t* kv_slot;    // [M][n_ctx] or null (beam search)
+  const int32_t* done;       // [M / group] or null: windows whose cross-attention is skipped
+  const float* x_in;         // f32 [M][d]: the embedding launch's output
+  float* x_out;              // f32 [M][d]: what the final LayerNorm launch reads (may alias x_in)
+  void* self_kv;             // T [L][2][rows][H][n_ctx][64]
+  int64_t kv_layer, kv_row;  // elements per K (or V) cache of a layer; per cache row
+  const void* xkv;           // T [2L][windows][H][t_len][64]
+  int64_t xkv_slab;
+  unsigned long long* g;     // ONE granule arena (8-byte {payload | tag}); the regions below are offsets into it
+  int32_t o_x, o_q, o_kv, o_a, o_qx, o_h, o_xp, o_mp;
+  unsigned* epoch;           // device word, 1 at first use; bumped by every completed launch
+  unsigned* abort_word;      // device word, 0; phase + 1 when a workgroup gave up waiting
+};
+// granules a state's arena needs for up to 16 rows; fills the offsets of p
+int64_t persist_layout(PersistParams* p);
+template <typename T> void launch_persist_step(const PersistParams& p, int grid, hipStream_t s);
+
 // device-side logits filter + arg-max (restates oracle ref_process_logits)
 struct SamplerParams {
   const float* logits;   // [batch][ld]

@@ -142,7 +142,7 @@ EXPORTS = [
     "ohw_vad_run",
     "ohw_pool_create", "ohw_pool_transcribe", "ohw_pool_last_text", "ohw_pool_last_tokens", "ohw_pool_last_quality",
     "ohw_dbg_counter", "ohw_dsp_denoise", "ohw_denoise_passthrough_engine", "ohw_preprocess_audio_ex", "ohw_pool_set_window_mode",
-    "ohw_pool_broadcast_note", "ohw_pool_create_synthetic", "ohw_pool_set_force_len", "ohw_pool_set_schedule", "ohw_engine_set_force_len",
+    "ohw_state_set_persistent", "ohw_pool_broadcast_note", "ohw_pool_create_synthetic", "ohw_pool_set_force_len", "ohw_pool_set_schedule", "ohw_engine_set_force_len",
     "ohw_pool_set_decode_policy", "ohw_pool_n_devices", "ohw_pool_broadcast_kind", "ohw_pool_engine", "ohw_pool_free",
 ]
 
@@ -304,6 +304,7 @@ def lib():
         L.ohw_greedy_ex.argtypes = [vp, C.POINTER(SampleParams), C.c_int, C.c_int, C.POINTER(GreedyResult)]
         L.ohw_state_set_logit_bias.argtypes = [vp, fp, C.c_int]
         L.ohw_state_set_batch_invariant.argtypes = [vp, C.c_int]
+        L.ohw_state_set_persistent.argtypes = [vp, C.c_int]
         L.ohw_beam_search.argtypes = [vp, C.POINTER(SampleParams), C.c_int, C.c_int, C.c_int, C.POINTER(BeamResult)]
         L.ohw_dbg_sample.argtypes = [vp, C.POINTER(SampleParams), fp, ip, C.c_int, ip, C.c_int, ip, fp, fp]
         L.ohw_decode_active.argtypes = [vp, ip, C.c_int, ip, C.c_int, ip, fp]
@@ -675,6 +676,10 @@ class State:
         else:
             b = np.ascontiguousarray(bias, dtype=np.float32)
             _check(lib().ohw_state_set_logit_bias(self.h, _fp(b), b.size))
+
+    def set_persistent(self, on: bool = True):
+        """ohw_state_set_persistent: the one-launch decoder step for at most 16 single-token rows (default on)"""
+        _check(lib().ohw_state_set_persistent(self.h, int(on)))
 
     def set_batch_invariant(self, on: bool = True):
         """ohw_state_set_batch_invariant: kernel variants picked from n_new alone - a window's result no longer depends on its batch"""
