@@ -596,6 +596,12 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
                 }
               }
               res = o / l;
+            } else {
+              // a finished window: nothing to merge, but the ORDER the merge gives must stay - o_a still holds the self-attention
+              // output phase C gathers, and G (which only waits for F) rewrites the residual granules phase D normalises.  The
+              // head's cross query under D's tag says every C task has run (D's LayerNorm read all of C's output)
+              int i1[1] = {p.o_qx + m * (d / 2) + h * 32 + (lane & 31)}; unsigned r1[1];
+              if (!poll<1>(p.g, i1, 1, tD, r1, ctl)) break;
             }
             const float res_n = __shfl_down(res, 1, 64);
             if ((lane & 1) == 0 && !*fail) gst(p.g + p.o_a + m * (d / 2) + h * 32 + lane / 2, tF, pack2<T>(res, res_n));

@@ -192,6 +192,8 @@ struct Dispatch {
   }
 };
 
+void persist_prepare(ohw_state* st);
+
 void state_alloc(ohw_state* st) {
   const ohw_ctx* c = st->ctx;
   const ohw_hparams& hp = c->hp;
@@ -266,6 +268,34 @@ void state_alloc(ohw_state* st) {
   st->tok_lp.alloc((size_t)B * (st->max_tokens + 1) * 4, true);
   st->nosp_prob.alloc((size_t)B * 4, true);
   for (auto& e : st->ev) HIP_CHECK(hipEventCreate(&e));
+  persist_prepare(st);
+}
+
+// the persistent decoder step's granule arena, epoch / abort words and per-layer pointer table (decode_persist.hip): made with
+// the state, never lazily - a first use inside a graph capture must not allocate or memset
+bool persist_dims_ok(const ohw_hparams& hp) {
+  return hp.n_text_state % 64 == 0 && hp.n_text_state <= 1280 && hp.n_text_head * 64 == hp.n_text_state;
+}
+void persist_prepare(ohw_state* st) {
+  const ohw_ctx* c = st->ctx;
+  const ohw_hparams& hp = c->hp;
+  if (!persist_dims_ok(hp) || st->ps_gran.p) return;
+  PersistParams q{};
+  q.d = hp.n_text_state; q.H = hp.n_text_head;
+  const int64_t n_gran = persist_layout(&q);
+  st->ps_gran.alloc((size_t)n_gran * 8, true);
+  st->ps_words.alloc(64, true);
+  const unsigned one = 1;
+  HIP_CHECK(hipMemcpy(st->ps_words.p, &one, 4, hipMemcpyHostToDevice));
+  std::vector<PersistLayer> lw((size_t)hp.n_text_layer);
+  for (int l = 0; l < hp.n_text_layer; ++l) {
+    const DecLayerW& w = c->dec[l];
+    lw[(size_t)l] = PersistLayer{w.wqkv.p, w.wo.p, w.wxq.p, w.wxo.p, w.w1.p, w.w2.p, w.bqkv.as<float>(), w.bo.as<float>(), w.bxq.as<float>(),
+                                 w.bxo.as<float>(), w.b1.as<float>(), w.b2.as<float>()};
+  }
+  st->ps_layers.alloc(lw.size() * sizeof(PersistLayer));
+  HIP_CHECK(hipMemcpy(st->ps_layers.p, lw.data(), lw.size() * sizeof(PersistLayer), hipMemcpyHostToDevice));
+  st->ps_layout = q;
 }
 
 template <typename T>
@@ -354,27 +384,9 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
   // layer.  Not under ohw_state_set_batch_invariant (a window's bits must then not depend on which path its batch takes), not
   // while a kernel class is being profiled, not on the experimental post-norm / split-K paths.
   if (st->persist && n_new == 1 && M <= 16 && kv_group <= 5 && M % kv_group == 0 && !st->batch_invariant && !pn && st->prof_class == 0 &&
-      st->ksplit_long == 1 && st->ksplit_short == 1 && d % 64 == 0 && d <= 1280 && H * 64 == d) {
+      st->ksplit_long == 1 && st->ksplit_short == 1 && st->ps_gran.p) {
     const int grid = std::max(1, std::min(st->stream_cus > 0 ? st->stream_cus : st->n_cu, 256));
     PersistParams q = st->ps_layout;
-    if (!st->ps_gran.p) {
-      q = PersistParams{};
-      q.d = d; q.H = H;
-      const int64_t n_gran = persist_layout(&q);
-      st->ps_gran.alloc((size_t)n_gran * 8, true);
-      st->ps_words.alloc(64, true);
-      const unsigned one = 1;
-      HIP_CHECK(hipMemcpy(st->ps_words.p, &one, 4, hipMemcpyHostToDevice));
-      std::vector<PersistLayer> lw((size_t)L);
-      for (int l = 0; l < L; ++l) {
-        const DecLayerW& w = c->dec[l];
-        lw[(size_t)l] = PersistLayer{w.wqkv.p, w.wo.p, w.wxq.p, w.wxo.p, w.w1.p, w.w2.p, w.bqkv.as<float>(), w.bo.as<float>(), w.bxq.as<float>(),
-                                     w.bxo.as<float>(), w.b1.as<float>(), w.b2.as<float>()};
-      }
-      st->ps_layers.alloc(lw.size() * sizeof(PersistLayer));
-      HIP_CHECK(hipMemcpy(st->ps_layers.p, lw.data(), lw.size() * sizeof(PersistLayer), hipMemcpyHostToDevice));
-      st->ps_layout = q;
-    }
     launch_embed<T>(c->emb.p, c->dec_pos.as<float>(), tok_src ? tok_src : st->step_tok.as<int32_t>(), n_past, st->dx.as<float>(), nullptr, nullptr, M, 1, d, s);
     const int Wn = M / kv_group;
     q.layers = st->ps_layers.as<PersistLayer>(); q.L = L; q.M = M; q.group = kv_group; q.d = d; q.H = H; q.n_ctx = C; q.t_len = Tn;
