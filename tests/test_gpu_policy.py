@@ -158,7 +158,9 @@ def test_temperature_ladder_matches_oracle_pass_by_pass(E, oracle, tmp_models):
               f"temperatures kept {[round(q['temperature'], 1) for q in eng.last_quality_ex()]}")
         total = [a + b for a, b in zip(total, (n_pass, n_steps, n_same))]
         if bias is None:
-            assert n_pass == 18 and all(abs(q["temperature"] - 1.0) < 1e-3 and q["failed"] for q in eng.last_quality_ex())
+            # every window runs the whole ladder; whether its LAST pass is marked failed is the oracle's call on the tokens that
+            # pass drew (checked window by window above): a draw at T = 1.0 may be end-of-text, which ends a pass legitimately
+            assert n_pass == 18 and all(abs(q["temperature"] - 1.0) < 1e-3 for q in eng.last_quality_ex())
         again = eng.transcribe(E.AudioBuffer(pcm, 16000))
         assert again.text == res.text                    # a fresh generator per window: the ladder is reproducible
         eng.close()
