@@ -468,6 +468,10 @@ def latency_figures(E, synth, ctx, hp, dtype, n_tokens):
     bound_ms = 1e3 * decoder_step_bytes(hp) / (PEAK_HBM_GBS * 1e9)
     out["b1_large_v3_ms_per_token"] = {"value": round(per_tok, 4), "hbm_bound_ms": round(bound_ms, 4), "frac": round(bound_ms / per_tok, 4),
                                        "window_ms": round(front_ms + dec_ms, 2), "front_end_ms": round(front_ms, 2), "tokens": n_tokens}
+    # the same decode through the one-launch persistent step (decode_persist.hip; off by default: its all-to-all hand-offs cost
+    # more than the kernel boundaries they replace) - recorded so that the rejected design has a driver-run number beside it
+    st.set_persistent(True)
+    out["b1_large_v3_ms_per_token"]["persistent_step_ms_per_token"] = round(med(lambda: st.greedy(1, p)) / n_tokens, 4)
     st.close()
     # (2) BASELINE config #5: one 5 s chunk, beam = 5, 48 decoder steps (procedural weights never finish early), mel + encoder +
     # cross K/V + beam search on one window (tools/streaming_latency.py drives the same through StreamingSession)

@@ -364,10 +364,13 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* p, int n_windows, in
  * Set on ohw_engine_state(e) it holds for every state ohw_engine_transcribe decodes on (the schedules' lane states too). */
 int ohw_state_set_logit_bias(ohw_state* st, const float* bias, int n);
 
-/* the persistent small-batch decoder step (default on; OHW_DEC_PERSIST=0 turns it off for new states): single-token steps
+/* the persistent small-batch decoder step (default OFF; OHW_DEC_PERSIST=1 turns it on for new states): single-token steps
  * of at most 16 rows - one utterance, the K rows of a beam search - run their 32 layers as ONE launch whose workgroups hand
- * activations to each other (openhush_amd/csrc/decode_persist.hip) instead of 8 launches per layer.  Never used under
- * ohw_state_set_batch_invariant.  Results are deterministic and a row's result does not depend on the other rows.        */
+ * activations to each other (openhush_amd/csrc/decode_persist.hip) instead of 8 launches per layer.  Correct (tests/
+ * test_gpu_persist.py) and slower than the launches on MI355X: every all-to-all hand-off between the 256 workgroups costs
+ * 3 - 6.5 us against 1.6 us of kernel boundary + 1.9 us of first-byte latency (profiles/r03_persist_trace.txt; large-v3,
+ * one row: 2.2 ms per token against 1.44).  Never used under ohw_state_set_batch_invariant.  Results are deterministic and
+ * a row's result does not depend on the other rows.                                                                        */
 int ohw_state_set_persistent(ohw_state* st, int on);
 
 /* batch-invariant decoding (default off): the decoder picks some kernel variants from the number of rows in flight - up to

@@ -94,6 +94,16 @@ __device__ __forceinline__ bool poll(const u64* g, const int (&idx)[N], int n, u
   }
 }
 
+#ifdef OHW_TRACE
+// instrumented build only (tools/persist_trace.py): 100 MHz stamps of one layer, per workgroup and phase.  Slots 0-3 by the first
+// IO wave (phase entered, inputs gathered, partial tiles ready, published), 4-7 by the first MFMA wave (weights requested,
+// inputs ready, weights landed, products done); the first task of a phase only
+__device__ unsigned long long ps_trace_buf[256 * 10 * 8];
+#define PTRACE(cond, ph, k) do { if ((cond) && (tid & 255) == 0 && wg < 256) ps_trace_buf[(wg * 10 + (ph)) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PTRACE(cond, ph, k) do { } while (0)
+#endif
+
 }  // namespace
 
 int64_t persist_layout(PersistParams* p) {
@@ -175,6 +185,8 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
           const int kind = ph < 3 ? ph : ph - 1;                     // A C D | E | G H I
           const Desc q = desc_of(lw, kind);
           const int n_tasks = q.n_tiles * q.nsl;
+          const int lph = ph == 0 ? 0 : ph == 1 ? 2 : ph == 2 ? 3 : ph == 4 ? 6 : ph == 5 ? 7 : 8;
+          (void)lph;
           for (int t = wg; t < n_tasks; t += G) {
             const int nt = t / q.nsl, sl = t % q.nsl;
             const int kb0 = (int)((int64_t)q.KB * sl / q.nsl), kb1 = (int)((int64_t)q.KB * (sl + 1) / q.nsl);
@@ -185,7 +197,13 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
               if (kk > kb1 - 1) kk = kb1 - 1;                    // clamped: unconditional loads, masked below
               wreg[u] = __builtin_nontemporal_load(&wt[(int64_t)kk * 64]);
             }
+            PTRACE(layer == p.L / 2 && t == wg, lph, 4);
             __syncthreads();                                      // #1: the tile is complete
+            PTRACE(layer == p.L / 2 && t == wg, lph, 5);
+#ifdef OHW_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PTRACE(layer == p.L / 2 && t == wg, lph, 6);
+#endif
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const unsigned char* y0 = tile + (lane & 15) * PS_TROW + (lane >> 4) * 16;
 #pragma unroll
@@ -200,6 +218,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
               acc = Ops::mfma16(wreg[u], a, acc);
             }
             part[iw * 64 + lane] = acc;
+            PTRACE(layer == p.L / 2 && t == wg, lph, 7);
             __syncthreads();                                      // #2: the four partial tiles are in LDS
           }
         } else {
@@ -227,7 +246,9 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
               }
             };
             if (!skip) load_kv(g_lo + iw);                       // in flight before the queries exist
+            PTRACE(layer == p.L / 2 && t == wg, 4, 4);
             __syncthreads();                                      // #1: the queries are in LDS
+            PTRACE(layer == p.L / 2 && t == wg, 4, 5);
             if (!skip) {
               float qv[PS_NQ][8], mrun[PS_NQ], lrun[PS_NQ], acc[PS_NQ][8];
 #pragma unroll
@@ -286,6 +307,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
                 }
               }
             }
+            PTRACE(layer == p.L / 2 && t == wg, 4, 7);
             __syncthreads();                                      // #2: the four waves' states are in LDS
           }
         }
@@ -370,6 +392,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
           for (int t = wg; t < n_tasks; t += G) {
             const int nt = t / q.nsl, sl = t % q.nsl;
             const int kb0 = (int)((int64_t)q.KB * sl / q.nsl), kb1 = (int)((int64_t)q.KB * (sl + 1) / q.nsl);
+            PTRACE(layer == p.L / 2 && t == wg, ph, 0);
             for (int r = iw; r < M; r += 4) {
               bool ok;
               if (kind == 0 || kind == 2 || kind == 4) ok = ln_row(r, t_in, kind == 0 && layer == 0);
@@ -377,8 +400,10 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
               else ok = gather_row16(p.o_h, 2 * d, r, kb0 * 32, kb1 * 32, t_in);
               if (!ok) break;
             }
+            PTRACE(layer == p.L / 2 && t == wg, ph, 1);
             __syncthreads();                                  // #1
             __syncthreads();                                  // #2
+            PTRACE(layer == p.L / 2 && t == wg, ph, 2);
             // thread = (lane' = it >> 2, reg = it & 3): D[n = 4 * (lane' >> 4) + reg][m = lane' & 15]
             const int ll = opq(it >> 2), reg = opq(it & 3);
             const float* pp = (const float*)part;
@@ -417,6 +442,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
             } else {
               if (live) gst(p.g + p.o_mp + (sl * 16 + m) * d + n, t_out, __float_as_uint(v));
             }
+            PTRACE(layer == p.L / 2 && t == wg, ph, 3);
           }
         } else if (ph == 1) {
           // ---------------- B: self-attention, one IO wave per (row, head) ----------------
@@ -427,6 +453,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
           for (int t = wg + G * iw; t < n_tasks; t += 4 * G) {
             const int m = t / H, h = t % H;
             const int part8 = opq(tid & 7), slot = opq((tid & 63) >> 3);
+            PTRACE(layer == p.L / 2 && t == wg, 1, 0);
             int n_old = p.n_past[m];                                         // cached positions 0 .. n_old - 1
             if (n_old > p.n_ctx - 1) n_old = p.n_ctx - 1;
             const char* kb = (const char*)(kc + ((int64_t)h * p.n_ctx << 6) + part8 * 8);
@@ -458,6 +485,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
               i12[8 + e] = p.o_kv + (m * 2 + 1) * (d / 2) + h * 32 + part8 * 4 + e;
             }
             if (!poll<12>(p.g, i12, 12, tA, r12, ctl)) break;
+            PTRACE(layer == p.L / 2 && t == wg, 1, 1);
             float qv[8], kn[8], vn8[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -526,6 +554,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
 #pragma unroll
               for (int e = 0; e < 4; ++e) gst(p.g + p.o_a + m * (d / 2) + h * 32 + part8 * 4 + e, tB, pack2<T>(acc[2 * e] * inv, acc[2 * e + 1] * inv));
             }
+            PTRACE(layer == p.L / 2 && t == wg, 1, 3);
           }
         } else if (ph == 4) {
           // ---------------- E: queries in, partial states out (the MFMA waves stream the K/V slice) ----------------
@@ -533,6 +562,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
           for (int t = wg; t < n_tasks; t += G) {
             const int w = t / (H * S), h = (t / S) % H, sl = t % S;
             const bool skip = p.done && p.done[w];
+            PTRACE(layer == p.L / 2 && t == wg, 4, 0);
             if (!skip) {
               // IO wave i takes rows i, i + 4 of the window: 32 granules per row -> 64 scaled floats in LDS
               for (int i = iw; i < NQ; i += 4) {
@@ -545,8 +575,10 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
                 if (lane < 32) { qs[i * 64 + 2 * lane] = lo * scl; qs[i * 64 + 2 * lane + 1] = hi * scl; }
               }
             }
+            PTRACE(layer == p.L / 2 && t == wg, 4, 1);
             __syncthreads();                                  // #1
             __syncthreads();                                  // #2
+            PTRACE(layer == p.L / 2 && t == wg, 4, 2);
             if (!skip) {
               for (int i = iw; i < NQ; i += 4) {
                 const float mn = fmaxf(fmaxf(red_m[i * 4 + 0], red_m[i * 4 + 1]), fmaxf(red_m[i * 4 + 2], red_m[i * 4 + 3]));
@@ -564,6 +596,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
                 }
               }
             }
+            PTRACE(layer == p.L / 2 && t == wg, 4, 3);
           }
         } else if (ph == 5) {
           // ---------------- F: merge of the key slices, one IO wave per (row, head) ----------------
@@ -571,6 +604,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
           for (int t = wg + G * iw; t < n_tasks; t += 4 * G) {
             const int m = t / H, h = t % H;
             const int lane = opq(tid & 63);
+            PTRACE(layer == p.L / 2 && t == wg, 5, 0);
             float res = 0.f;
             if (!(p.done && p.done[m / p.group])) {
               constexpr int MS = 16;
@@ -605,11 +639,13 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
             }
             const float res_n = __shfl_down(res, 1, 64);
             if ((lane & 1) == 0 && !*fail) gst(p.g + p.o_a + m * (d / 2) + h * 32 + lane / 2, tF, pack2<T>(res, res_n));
+            PTRACE(layer == p.L / 2 && t == wg, 5, 3);
           }
         } else {
           // ---------------- J: x += b2 + the slices' partial sums (fixed order), one IO wave per 16 columns ----------------
           const bool last = layer == p.L - 1;
           for (int t = wg + G * iw; t < nt_d; t += 4 * G) {
+            PTRACE(layer == p.L / 2 && t == wg, 9, 0);
             for (int e = opq(lane); e < 16 * M; e += 64) {
               const int m = e >> 4, n = t * 16 + (e & 15);
               // the partials carry I's tag, the residual G's: the partials arrive last, so they are waited for first
@@ -627,6 +663,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void persist_step_kernel(PersistPara
                 if (last) p.x_out[(int64_t)m * d + n] = x;
               }
             }
+            PTRACE(layer == p.L / 2 && t == wg, 9, 3);
           }
         }
       }
@@ -654,3 +691,12 @@ template void launch_persist_step<bf16_t>(const PersistParams&, int, hipStream_t
 template void launch_persist_step<f16_t>(const PersistParams&, int, hipStream_t);
 
 }  // namespace ohw
+
+#ifdef OHW_TRACE
+extern "C" int ohw_dbg_persist_trace_read(unsigned long long* out, int cap) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  const int n = cap < 256 * 10 * 8 ? cap : 256 * 10 * 8;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ohw::ps_trace_buf), (size_t)n * 8) != hipSuccess) return -1;
+  return n;
+}
+#endif

@@ -134,7 +134,7 @@ struct ohw_state {
   // the persistent small-batch decoder step (decode_persist.hip): per-layer pointer table, granule arena, epoch / abort words
   DevBuf ps_layers, ps_gran, ps_words;
   PersistParams ps_layout{};         // region offsets of the arena
-  bool persist = true;               // OHW_DEC_PERSIST / ohw_state_set_persistent
+  bool persist = false;              // OHW_DEC_PERSIST / ohw_state_set_persistent (off: measured slower than the launches)
   int persist_launches = 0;
   int n_cu = 0;
   int step_captures = 0;
@@ -234,7 +234,7 @@ void state_alloc(ohw_state* st) {
   // stalls inside a replay (tools/lane_gap_analysis.py) - and a lane's first call no longer waits, at its capture, for the
   // other lanes to leave the library
   st->graph_max_batch = env_int("OHW_GRAPH_MAX_BATCH", 32, 1, 1 << 20);
-  st->persist = env_int("OHW_DEC_PERSIST", 1, 0, 1) != 0;
+  st->persist = env_int("OHW_DEC_PERSIST", 0, 0, 1) != 0;
   (void)hipDeviceGetAttribute(&st->n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
   st->postnorm = env_int("OHW_DEC_POSTNORM", 0, 0, 1) != 0 && dec_ksplit_long() == 1 && dec_ksplit_short() == 1 && dt % 32 == 0;
   st->dx16.alloc(m_tiles * dt * 2, true);
@@ -1037,6 +1037,9 @@ int ohw_greedy(ohw_state* st, const ohw_sample_params* sp, int batch, int32_t* t
   return ohw_greedy_ex(st, sp, batch, max_tokens, &r);
 }
 
+// OHW_DEBUG_MARKS=1: progress lines on stderr (which HIP call a tool died under)
+#define BMARK(what, i) do { static const bool on_ = env_int("OHW_DEBUG_MARKS", 0, 0, 1) != 0; if (on_) { std::fprintf(stderr, "[ohw beam] %s %d\n", what, (int)(i)); std::fflush(stderr); } } while (0)
+
 int ohw_beam_search(ohw_state* st, const ohw_sample_params* sp, int n_windows, int beam_size, int max_tokens, const ohw_beam_result* res) {
   return guard([&] {
     if (!st || !sp || !res || !res->tokens || !res->n_tokens) throw Error(OHW_E_INVALID_ARG, "null argument");
@@ -1130,10 +1133,13 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* sp, int n_windows, i
             CaptureGate gate;
             struct StreamSwap { ohw_state* st; hipStream_t keep; ~StreamSwap() { st->stream = keep; } } swap{st, st->stream};
             st->stream = cap;
+            BMARK("capture begin", q);
             HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
             try {
               run_decoder_step<T>(st, R, 1, st->next_tok.as<int32_t>(), K, bq.kv_slot, bq.win_done);
+              BMARK("decoder step captured", q);
               launch_beam_step(pq, bq, W, 0, cap);
+              BMARK("beam step captured", q);
             } catch (...) {
               hipGraph_t g = nullptr;
               (void)hipStreamEndCapture(cap, &g);
@@ -1141,7 +1147,9 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* sp, int n_windows, i
               throw;
             }
             HIP_CHECK(hipStreamEndCapture(cap, &ng.graph[q]));
+            BMARK("capture ended", q);
             HIP_CHECK(hipGraphInstantiate(&ng.exec[q], ng.graph[q], nullptr, nullptr, 0));
+            BMARK("instantiated", q);
           }
         } catch (...) {
           drop();
@@ -1157,7 +1165,9 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* sp, int n_windows, i
       for (int it = 1; it < n_max; ++it) {
         const int q = it & 1;
         if (use_graph) {
+          BMARK("graph launch", it);
           HIP_CHECK(hipGraphLaunch(exec[q], s));
+          BMARK("graph launched", it);
         } else {
           SamplerParams pq; BeamParams bq;
           params(q, &pq, &bq);

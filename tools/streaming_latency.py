@@ -45,7 +45,7 @@ def main():
         lat.append(time.perf_counter() - t0)
         ses.tracker.add_result(r)
         ses.tracker.take_ready()
-    warm = lat[2:]                    # the first chunks capture the two beam-step graphs
+    warm = lat[2:] or lat[-1:]        # the first chunks capture the two beam-step graphs (a one-chunk run - profiling - reports that chunk)
     print(json.dumps({"workload": f"{a.model} streaming, {a.chunk:g} s chunks, beam {a.beam}, {a.tokens} decoder steps per chunk, {a.dtype}",
                       "first_chunk_ms": round(1e3 * lat[0], 2), "chunk_latency_ms": {"mean": round(1e3 * float(np.mean(warm)), 2),
                       "min": round(1e3 * min(warm), 2), "max": round(1e3 * max(warm), 2)},
