@@ -32,6 +32,17 @@ constexpr int G2_WOFF = 32768;
 
 __device__ __forceinline__ int g2_key(int row) { return (row >> 1) & 7; }
 
+#ifdef OHW_TRACE
+// instrumented build only (tools/gemm_trace.py): per workgroup {tile id, XCC_ID | CU id, entry, first K-tile landed, main loop
+// done, exit} on the 100 MHz clock
+constexpr unsigned G2_TRACE_CAP = 1u << 16;
+__device__ unsigned long long g2_trace_buf[G2_TRACE_CAP * 12];
+__device__ unsigned g2_trace_n;
+#define G2T(k) do { if (tid == 0 && g2_slot < G2_TRACE_CAP) g2_trace_buf[g2_slot * 12 + (k)] = wall_clock64(); } while (0)
+#else
+#define G2T(k) do { } while (0)
+#endif
+
 template <typename T, int EPI>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   using Ops = TypeOps<T>;
@@ -41,6 +52,20 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+#ifdef OHW_TRACE
+  unsigned g2_slot = G2_TRACE_CAP;
+  if (tid == 0) {
+    g2_slot = atomicAdd(&g2_trace_n, 1u);
+    if (g2_slot < G2_TRACE_CAP) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g2_trace_buf[g2_slot * 12 + 0] = blockIdx.x;
+      g2_trace_buf[g2_slot * 12 + 1] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+    }
+  }
+  G2T(2);
+#endif
 
   const unsigned n_tiles_n = (unsigned)(p.N / G2_BN);
   const unsigned n_tiles_m = (unsigned)((p.M + G2_BM - 1) / G2_BM);
@@ -107,6 +132,15 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   const int a_row = (wm * 128 + fr) * 128;
   const int w_row = G2_WOFF + (wn * 64 + fr) * 128;
 
+  // the lane's 16 bias values, requested before the main loop (four 16-byte loads): at the head of the epilogue they were 16 branchy
+  // dword loads and a full memory round trip in every tile (gemm_trace: stores issued 4.2 us after the last MFMA)
+  const int64_t nb = n0 + wn * 64 + fq * 16;
+  f32x4 bias4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = *(const f32x4*)(p.bias + nb + 4 * j);
+  }
+
   // A "phase" P = 2*kt + h consumes k-half h of K-tile kt (32 MFMAs per wave) from stage kt & 1.
   //
   // The two waves that share a SIMD (wave w and w + 4, i.e. wm = 0 / 1) run the SAME program shifted by one
@@ -154,6 +188,9 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
     // group 0: interval 2P reads phase P, interval 2P+1 computes it
     for (int P = 0; P < NP; ++P) {
       open_even(P);
+#ifdef OHW_TRACE
+      if (P == 0) G2T(3);
+#endif
       read_frags(P);
       if ((P & 1) == 0 && (P >> 1) + 1 < KT) issue_tile((P >> 1) + 1);   // the other stage: its readers are behind the barrier above
       __builtin_amdgcn_sched_barrier(0);
@@ -176,61 +213,138 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
     }
   }
 
+  G2T(4);
   // ---- epilogue: lane (fq, fr) holds, for each mi, columns n0 + wn*64 + fq*16 + [0,16) of row m ----
-  const int64_t nb = n0 + wn * 64 + fq * 16;
   float bias[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) bias[j] = p.bias ? p.bias[nb + j] : 0.0f;
+  for (int j = 0; j < 16; ++j) bias[j] = bias4[j >> 2][j & 3];
   if constexpr (EPI == EPI_BIAS_RESID_F32) {
     // fp32 residual read-modify-write through LDS.  In the MFMA layout a lane owns 64 B of a row and a wave-instruction
     // touches 16 rows x 4 x 16 B: 32 half-used cache lines per instruction - a tile's 512 KB of residual traffic took
     // ~35 us that way (the K = 1280 out-projection ran at half the rate of the same shape with a 16-bit store).  The
     // finished tile goes to the (now free) LDS, 128 rows at a time, chunk-swizzled by row, and every wave then walks
     // whole rows: 64 lanes x 16 B = one 1-KiB row of the tile = 8 full lines per instruction.
-    __syncthreads();                       // every wave is past its last fragment read; no DMA is outstanding
     float* outf = (float*)p.out;
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-      if (wm == half) {
+    // Two rounds; in round r EVERY wave sends its accumulator rows mi = 4r .. 4r + 3 to LDS (local row wm * 64 + q * 16 + fr of 128,
+    // 1 KiB each), then wave w walks local rows w * 16 + [0, 16) whole: tile row (w >> 2) * 128 + r * 64 + (w & 3) * 16 + i.
+    // The old values of a round's 16 rows are requested in ONE go - round 0's before the tile goes to LDS, round 1's as soon as
+    // round 0's accumulator registers are free - behind raw barriers that leave them in flight (a __syncthreads drains every
+    // outstanding load).  Measured (tools/gemm_trace.py, 96 windows): 15 us per tile either way - the 512 KB a tile reads and
+    // writes here move at the 35 GB/s ONE CU gets from beyond its L2 while the other CUs run their main loops, whatever the
+    // order of the requests; moving the add into the following LayerNorm launch would cost that launch more (it runs at HBM
+    // rate on every CU: + 1.1 GB per launch at 96 windows = 0.18 ms against 0.11 ms saved here).
+    auto row_ptr = [&](int r, int i) -> float* {
+      int64_t m = m0 + (wave >> 2) * 128 + r * 64 + (wave & 3) * 16 + i;
+      if (m > p.M - 1) m = p.M - 1;                 // unconditional loads (clamped row), masked stores
+      int64_t bb = 0, rr = m;
+      if (p.rows_per_batch < p.M) { const unsigned q = (unsigned)m / (unsigned)p.rows_per_batch; bb = q; rr = m - (int64_t)q * p.rows_per_batch; }
+      return outf + bb * p.c_batch_stride + rr * p.ldc + n0 + lane * 4;
+    };
+    auto raw_barrier = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto to_lds = [&](int r) {
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-          const int row = mi * 16 + fr;
+      for (int q = 0; q < 4; ++q) {
+        const int row = wm * 64 + q * 16 + fr;
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
-            const int chunk = (wn * 16 + fq * 4 + ni) ^ (row & 15);
-            f32x4 v4 = acc[mi][ni];
-            v4.x += bias[4 * ni]; v4.y += bias[4 * ni + 1]; v4.z += bias[4 * ni + 2]; v4.w += bias[4 * ni + 3];
-            *(f32x4*)(smem + row * 1024 + chunk * 16) = v4;
-          }
+        for (int ni = 0; ni < 4; ++ni) {
+          const int chunk = (wn * 16 + fq * 4 + ni) ^ (row & 15);
+          f32x4 v4 = acc[4 * r + q][ni];
+          v4.x += bias[4 * ni]; v4.y += bias[4 * ni + 1]; v4.z += bias[4 * ni + 2]; v4.w += bias[4 * ni + 3];
+          *(f32x4*)(smem + row * 1024 + chunk * 16) = v4;
         }
       }
-      __syncthreads();
+    };
+    auto finish = [&](int r, f32x4 (&old)[16]) {
 #pragma unroll
-      for (int i0 = 0; i0 < 16; i0 += 8) {
-        f32x4 old[8];
-        float* optr[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          int64_t m = m0 + half * 128 + wave * 16 + i0 + i;
-          if (m > p.M - 1) m = p.M - 1;               // unconditional loads (clamped row), masked stores
-          int64_t b = 0, rr = m;
-          if (p.rows_per_batch < p.M) { const unsigned bb = (unsigned)m / (unsigned)p.rows_per_batch; b = bb; rr = m - (int64_t)bb * p.rows_per_batch; }
-          optr[i] = outf + b * p.c_batch_stride + rr * p.ldc + n0 + lane * 4;
-          old[i] = *(const f32x4*)optr[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int r = wave * 16 + i0 + i;
-          if (m0 + half * 128 + r >= p.M) continue;
-          const f32x4 v4 = *(const f32x4*)(smem + r * 1024 + ((lane ^ (r & 15)) << 4));
-          f32x4 o4 = old[i];
-          o4.x += v4.x; o4.y += v4.y; o4.z += v4.z; o4.w += v4.w;
-          *(f32x4*)optr[i] = o4;
-        }
+      for (int i = 0; i < 16; ++i) {
+        const int lr = wave * 16 + i;
+        if (m0 + (wave >> 2) * 128 + r * 64 + (wave & 3) * 16 + i >= p.M) continue;
+        const f32x4 v4 = *(const f32x4*)(smem + lr * 1024 + ((lane ^ (lr & 15)) << 4));
+        f32x4 o4 = old[i];
+        o4.x += v4.x; o4.y += v4.y; o4.z += v4.z; o4.w += v4.w;
+        *(f32x4*)row_ptr(r, i) = o4;
       }
-      __syncthreads();
-    }
+    };
+    f32x4 old0[16], old1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) old0[i] = *(const f32x4*)row_ptr(0, i);
+    G2T(6);
+    raw_barrier();                         // every wave is past its last fragment read; no DMA is outstanding
+    to_lds(0);
+    raw_barrier();
+    G2T(7);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) old1[i] = *(const f32x4*)row_ptr(1, i);      // into the registers acc[0..3] no longer need
+    finish(0, old0);
+    G2T(8);
+    raw_barrier();                         // round 0 has been read out of LDS
+    to_lds(1);
+    raw_barrier();
+    G2T(9);
+    finish(1, old1);
+    G2T(10);
+    G2T(11);
+#ifdef OHW_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G2T(5);
+#endif
     return;
+  }
+  if constexpr (EPI == EPI_BIAS_T || EPI == EPI_BIAS_GELU_T) {
+    if (p.lds_store) {
+      // 16-bit row-major output through the (now free) LDS: in the MFMA layout a store instruction writes 16 rows x 4 separate
+      // 16-byte pieces; here every instruction writes two whole 512-byte rows of the tile.  Row pitch 512 B, the 32 chunks of a
+      // row XOR-swizzled with row & 15 (conflict-free both ways).
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // every wave is past its last fragment read; no DMA is outstanding
+      __builtin_amdgcn_sched_barrier(0);
+      G2T(9);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        const int row = wm * 128 + mi * 16 + fr;
+        float v[16];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[ni * 4 + j] = acc[mi][ni][j] + bias[ni * 4 + j];
+        if constexpr (EPI == EPI_BIAS_GELU_T) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
+        }
+        u32x4 lo, hi;
+        lo.x = pack2<T>(v[0], v[1]); lo.y = pack2<T>(v[2], v[3]); lo.z = pack2<T>(v[4], v[5]); lo.w = pack2<T>(v[6], v[7]);
+        hi.x = pack2<T>(v[8], v[9]); hi.y = pack2<T>(v[10], v[11]); hi.z = pack2<T>(v[12], v[13]); hi.w = pack2<T>(v[14], v[15]);
+        const int c0 = wn * 8 + fq * 2;
+        *(u32x4*)(smem + row * 512 + ((c0 ^ fr) << 4)) = lo;
+        *(u32x4*)(smem + row * 512 + (((c0 + 1) ^ fr) << 4)) = hi;
+      }
+      G2T(7);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      G2T(8);
+      T* outp = (T*)p.out;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = wave * 32 + 2 * i + (lane >> 5);
+        const int64_t m = m0 + r;
+        if (m >= p.M) continue;
+        int64_t bb = 0, rr = m;
+        if (p.rows_per_batch < p.M) { const unsigned q = (unsigned)m / (unsigned)p.rows_per_batch; bb = q; rr = m - (int64_t)q * p.rows_per_batch; }
+        const u32x4 d4 = *(const u32x4*)(smem + r * 512 + (((lane & 31) ^ (r & 15)) << 4));
+        *(u32x4*)(outp + bb * p.c_batch_stride + rr * p.ldc + n0 + (lane & 31) * 8) = d4;
+      }
+#ifdef OHW_TRACE
+      G2T(6);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      G2T(5);
+#endif
+      return;
+    }
   }
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
@@ -243,6 +357,11 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
       for (int j = 0; j < 4; ++j) v[ni * 4 + j] = acc[mi][ni][j] + bias[ni * 4 + j];
     gemm_store_row<T, EPI>(p, m, nb, v);
   }
+#ifdef OHW_TRACE
+  G2T(6);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  G2T(5);
+#endif
 }
 
 template <typename T, int EPI>
@@ -251,6 +370,8 @@ static void launch256_one(const GemmParams& p, hipStream_t stream) {
   ensure_dynamic_lds((const void*)gemm256_kernel<T, EPI>, 2 * G2_STAGE);
   GemmParams q = p;
   static const int gm_env = [] { const char* e = getenv("OHW_GEMM_GM"); return e ? atoi(e) : 0; }();
+  static const int lds_store_env = [] { const char* e = getenv("OHW_GEMM_LDS_STORE"); return e ? atoi(e) : 1; }();
+  q.lds_store = lds_store_env;
   q.group_m = gm_env > 0 ? gm_env : 6;   // 6: 1 % faster than 8 at 32 and at 96 windows per pass (round 2 sweep: 4, 6, 8, 16)
   hipLaunchKernelGGL((gemm256_kernel<T, EPI>), dim3(nwg), dim3(G2_THREADS), 2 * G2_STAGE, stream, q);
   HIP_CHECK(hipGetLastError());
@@ -276,3 +397,18 @@ template void launch_gemm256<bf16_t>(const GemmParams&, int, hipStream_t);
 template void launch_gemm256<f16_t>(const GemmParams&, int, hipStream_t);
 
 }  // namespace ohw
+
+#ifdef OHW_TRACE
+// instrumented build only: copy the per-workgroup records out and reset (returns the number of records)
+extern "C" int ohw_dbg_gemm_trace_read(unsigned long long* out, int cap_records) {
+  unsigned n = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(ohw::g2_trace_n), sizeof(n)) != hipSuccess) return -1;
+  if (n > ohw::G2_TRACE_CAP) n = ohw::G2_TRACE_CAP;
+  if ((int)n > cap_records) n = (unsigned)cap_records;
+  if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(ohw::g2_trace_buf), (size_t)n * 96) != hipSuccess) return -1;
+  const unsigned zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(ohw::g2_trace_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+  return (int)n;
+}
+#endif
