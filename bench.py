@@ -349,6 +349,21 @@ def main():
     for _ in range(args.steps):
         step()
     launches, k_ms, work = st.profile_end()
+    # the MFMA class once more at the shape the TIMED schedule launches it: one front-end pass over a lane's MG x B windows (the
+    # 32-window figures above pay 8 % for a last round of 256-row tiles that is two thirds empty)
+    lane_pass = None
+    if pipe and G > 1 and MG > 1:
+        s_ = pst[0]
+        s_.set_stream(full.ptr)
+        lane_pass = {"windows": MG * B}
+        for cls, key in ((1, "gemm"), (2, "attention")):
+            s_.profile_begin(cls)
+            s_.mel_device(pcm_all.data_ptr(), pcm_all.shape[1], n_samples * MG, E.OHW_MEL_ZERO_TAIL)
+            s_.encode(MG * B)
+            _, ms_c, w_c = s_.profile_end()
+            lane_pass[key + "_ms_per_step"] = round(ms_c / MG, 3)
+            lane_pass[key + "_tflops"] = round(w_c / (ms_c * 1e-3) / 1e12, 1) if ms_c > 0 else 0.0
+        lane_pass["gemm_frac"] = round(lane_pass["gemm_tflops"] / PEAK_MFMA_TFLOPS, 4)
 
     dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if use_dist:
@@ -382,7 +397,9 @@ def main():
         if class_totals.get(1, 0) > 0 and class_work.get(1, 0) > 0:
             tf = class_work[1] / (class_totals[1] * 1e-3) / 1e12
             mfma = {"kernel": PROF_NAMES[1], "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / PEAK_MFMA_TFLOPS, 4), "ms_per_step": round(class_totals[1], 3)}
+                    "frac": round(tf / PEAK_MFMA_TFLOPS, 4), "ms_per_step": round(class_totals[1], 3),
+                    "at_the_timed_schedules_pass": lane_pass,
+                    "note": "the chip runs this kernel at its 1.39 kW cap and 2.05 GHz (tools/gemm_power_probe.py): the dense peak at that clock is 2.14 PFLOP/s"}
         roof.update({"kernel": PROF_NAMES[prof_class], "launches": launches, "avg_launch_us": round(1e3 * k_ms / max(1, launches), 2),
                      "kernel_ms_per_step": round(k_ms / args.steps, 3),
                      "class_ms_per_step": {PROF_NAMES[k]: round(v, 3) for k, v in class_totals.items()}})
