@@ -26,7 +26,6 @@ struct GemmParams {
   int32_t d_model, n_head, t_len, batch;   // batch = windows of the decode batch the K/V belong to
   int32_t batch_offset;                    // first window of this GEMM's rows inside that decode batch (ohw_encode_slice)
   int32_t group_m;    // gemm256: m-tiles per L2-locality group (set by the launcher)
-  int32_t lds_store;  // gemm256, 16-bit row-major outputs: the finished tile goes through LDS so that every store instruction writes whole rows (set by the launcher)
 };
 
 // N % 128 == 0, K % 64 == 0, lda/ldc/strides multiples of 8 elements (16-byte rows)

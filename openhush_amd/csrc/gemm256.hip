@@ -18,6 +18,7 @@
 //     wave's first read interval after the barrier that retired the stage's last readers; the data is needed two
 //     phase-times later, behind s_waitcnt vmcnt(0) (nothing younger is in flight at that point) + raw s_barrier.
 // Roofline: MFMA.
+#include <algorithm>
 #include <cstdlib>
 
 #include "gemm.hpp"
@@ -52,34 +53,14 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-#ifdef OHW_TRACE
-  unsigned g2_slot = G2_TRACE_CAP;
-  if (tid == 0) {
-    g2_slot = atomicAdd(&g2_trace_n, 1u);
-    if (g2_slot < G2_TRACE_CAP) {
-      unsigned hw, xcc;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      g2_trace_buf[g2_slot * 12 + 0] = blockIdx.x;
-      g2_trace_buf[g2_slot * 12 + 1] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
-    }
-  }
-  G2T(2);
-#endif
 
   const unsigned n_tiles_n = (unsigned)(p.N / G2_BN);
   const unsigned n_tiles_m = (unsigned)((p.M + G2_BM - 1) / G2_BM);
   const unsigned nwg = n_tiles_n * n_tiles_m;
-  const unsigned lid = xcd_remap(blockIdx.x, nwg);
-  // tile order inside an XCD's contiguous range: groups of GM m-tiles (6; 8 in round 1), m fastest, so that the ~32 workgroups
-  // an XCD runs at a time cover GM m-tiles x 32 / GM n-tiles (about 12 operand panels through its 4-MiB L2 instead of 17)
-  const unsigned GM = (unsigned)p.group_m;
-  const unsigned per_group = GM * n_tiles_n;
-  const unsigned grp_id = lid / per_group, in_grp = lid % per_group;
-  const unsigned g_first = grp_id * GM;
-  const unsigned g_size = n_tiles_m - g_first < GM ? n_tiles_m - g_first : GM;
-  const int64_t m0 = (int64_t)(g_first + in_grp % g_size) * G2_BM;
-  const int64_t n0 = (int64_t)(in_grp / g_size) * G2_BN;
+  // Tiles per workgroup: ONE (grid = tiles) or - the persistent form, K-tile count even - tiles d, d + G, d + 2G, ... of a grid of G
+  // workgroups, one per CU (G a multiple of 8, so d % 8 - the XCD under round-robin placement - is the same for all of a
+  // workgroup's tiles and the order in which an XCD meets its tiles is the order the dispatcher would have handed them out in).
+  const unsigned G = gridDim.x;
 
   const T* __restrict__ A = (const T*)p.A;
   const T* __restrict__ W = (const T*)p.W;
@@ -87,22 +68,34 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   // ---- staging: per stage each operand is 32 blocks of 1 KiB (8 rows x 128 B); wave w fills blocks 4w .. 4w+3.
   // lane -> row r = lane>>3 of the block, LDS chunk c = lane&7, holding data chunk c ^ key(row).
   const int sr = lane >> 3, sc = lane & 7;
-  const T* a_src[4];
-  const T* w_src[4];
+  unsigned a_off[4], w_off[4];       // BYTE offsets of this lane's four source rows from A / W (< 4 GiB, checked by the launcher): 8 registers, not 16
+  int64_t m0 = 0, n0 = 0;
+  auto tile_setup = [&](unsigned d) {
+    const unsigned lid = xcd_remap(d, nwg);
+    // tile order inside an XCD's contiguous range: groups of GM m-tiles (6; 8 in round 1), m fastest, so that the ~32 workgroups
+    // an XCD runs at a time cover GM m-tiles x 32 / GM n-tiles (about 12 operand panels through its 4-MiB L2 instead of 17)
+    const unsigned GM = (unsigned)p.group_m;
+    const unsigned per_group = GM * n_tiles_n;
+    const unsigned grp_id = lid / per_group, in_grp = lid % per_group;
+    const unsigned g_first = grp_id * GM;
+    const unsigned g_size = n_tiles_m - g_first < GM ? n_tiles_m - g_first : GM;
+    m0 = (int64_t)(g_first + in_grp % g_size) * G2_BM;
+    n0 = (int64_t)(in_grp / g_size) * G2_BN;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int R = (wave * 4 + j) * 8 + sr;          // LDS row 0..255
-    const int dchunk = sc ^ g2_key(R);
-    int64_t m = m0 + R;
-    if (m > p.M - 1) m = p.M - 1;
-    int64_t b = 0, rr = m;
-    if (p.rows_per_batch < p.M) { const unsigned bb = (unsigned)m / (unsigned)p.rows_per_batch; b = bb; rr = m - (int64_t)bb * p.rows_per_batch; }
-    a_src[j] = A + b * p.a_batch_stride + rr * p.lda + dchunk * 8;
-    // LDS row rho (inside each 64-row block: rho = ni*16 + q*4 + jj) holds W row q*16 + ni*4 + jj
-    const int rl = R & 63;
-    const int nl = (((rl >> 2) & 3) << 4) + ((rl >> 4) << 2) + (rl & 3);
-    w_src[j] = W + (n0 + (R & ~63) + nl) * p.K + dchunk * 8;
-  }
+    for (int j = 0; j < 4; ++j) {
+      const int R = (wave * 4 + j) * 8 + sr;          // LDS row 0..255
+      const int dchunk = sc ^ g2_key(R);
+      int64_t m = m0 + R;
+      if (m > p.M - 1) m = p.M - 1;
+      int64_t b = 0, rr = m;
+      if (p.rows_per_batch < p.M) { const unsigned bb = (unsigned)m / (unsigned)p.rows_per_batch; b = bb; rr = m - (int64_t)bb * p.rows_per_batch; }
+      a_off[j] = (unsigned)((b * p.a_batch_stride + rr * p.lda + dchunk * 8) * 2);
+      // LDS row rho (inside each 64-row block: rho = ni*16 + q*4 + jj) holds W row q*16 + ni*4 + jj
+      const int rl = R & 63;
+      const int nl = (((rl >> 2) & 3) << 4) + ((rl >> 4) << 2) + (rl & 3);
+      w_off[j] = (unsigned)(((n0 + (R & ~63) + nl) * p.K + dchunk * 8) * 2);
+    }
+  };
   const int KT = (int)(p.K / G2_BK);
 
   // the 8 DMA instructions of this wave for K-tile kt
@@ -111,19 +104,13 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
     const int buf = (kt & 1) * G2_STAGE;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + koff),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)A + (size_t)(a_off[j] + (unsigned)(koff * 2))),
                                        (__attribute__((address_space(3))) void*)(smem + buf + (wave * 4 + j) * 1024), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + koff),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W + (size_t)(w_off[j] + (unsigned)(koff * 2))),
                                        (__attribute__((address_space(3))) void*)(smem + buf + G2_WOFF + (wave * 4 + j) * 1024), 16, 0, 0);
   };
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // fragment read offsets inside a stage: row = tile row + (lane & 15), chunk (4h + (lane >> 4)) ^ key(row);
   // tile rows start at multiples of 16, so key(row) depends on (lane & 15) only
@@ -131,15 +118,6 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   const int fkey = g2_key(fr);
   const int a_row = (wm * 128 + fr) * 128;
   const int w_row = G2_WOFF + (wn * 64 + fr) * 128;
-
-  // the lane's 16 bias values, requested before the main loop (four 16-byte loads): at the head of the epilogue they were 16 branchy
-  // dword loads and a full memory round trip in every tile (gemm_trace: stores issued 4.2 us after the last MFMA)
-  const int64_t nb = n0 + wn * 64 + fq * 16;
-  f32x4 bias4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  if (p.bias) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bias4[j] = *(const f32x4*)(p.bias + nb + 4 * j);
-  }
 
   // A "phase" P = 2*kt + h consumes k-half h of K-tile kt (32 MFMAs per wave) from stage kt & 1.
   //
@@ -153,8 +131,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   // computes; the data is first read in interval 4kt + 8, behind vmcnt(0) at the barrier that opens it (each wave's
   // youngest DMA group at that point is that tile's).
   const int NP = 2 * KT;
-  issue_tile(0);
-
+  f32x4 acc[8][4];
   vec8 fw[4], fa[8];
   auto read_frags = [&](int P) {
     const int cur = ((P >> 1) & 1) * G2_STAGE;
@@ -184,184 +161,247 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  if (wm == 0) {
-    // group 0: interval 2P reads phase P, interval 2P+1 computes it
-    for (int P = 0; P < NP; ++P) {
-      open_even(P);
-#ifdef OHW_TRACE
-      if (P == 0) G2T(3);
-#endif
-      read_frags(P);
-      if ((P & 1) == 0 && (P >> 1) + 1 < KT) issue_tile((P >> 1) + 1);   // the other stage: its readers are behind the barrier above
-      __builtin_amdgcn_sched_barrier(0);
-      open_odd();
-      compute();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    open_even(NP);   // the partner group's last compute interval
-  } else {
-    // group 1: one interval behind: interval 2P+1 reads phase P, interval 2P+2 computes it
-    open_even(0);
-    for (int P = 0; P < NP; ++P) {
-      open_odd();
-      read_frags(P);
-      if ((P & 1) == 0 && (P >> 1) + 1 < KT) issue_tile((P >> 1) + 1);   // this wave's share, one interval after the partner group's
-      __builtin_amdgcn_sched_barrier(0);
-      open_even(P + 1);
-      compute();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
+  auto raw_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
 
-  G2T(4);
-  // ---- epilogue: lane (fq, fr) holds, for each mi, columns n0 + wn*64 + fq*16 + [0,16) of row m ----
-  float bias[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) bias[j] = bias4[j >> 2][j & 3];
-  if constexpr (EPI == EPI_BIAS_RESID_F32) {
-    // fp32 residual read-modify-write through LDS.  In the MFMA layout a lane owns 64 B of a row and a wave-instruction
-    // touches 16 rows x 4 x 16 B: 32 half-used cache lines per instruction - a tile's 512 KB of residual traffic took
-    // ~35 us that way (the K = 1280 out-projection ran at half the rate of the same shape with a 16-bit store).  The
-    // finished tile goes to the (now free) LDS, 128 rows at a time, chunk-swizzled by row, and every wave then walks
-    // whole rows: 64 lanes x 16 B = one 1-KiB row of the tile = 8 full lines per instruction.
-    float* outf = (float*)p.out;
-    // Two rounds; in round r EVERY wave sends its accumulator rows mi = 4r .. 4r + 3 to LDS (local row wm * 64 + q * 16 + fr of 128,
-    // 1 KiB each), then wave w walks local rows w * 16 + [0, 16) whole: tile row (w >> 2) * 128 + r * 64 + (w & 3) * 16 + i.
-    // The old values of a round's 16 rows are requested in ONE go - round 0's before the tile goes to LDS, round 1's as soon as
-    // round 0's accumulator registers are free - behind raw barriers that leave them in flight (a __syncthreads drains every
-    // outstanding load).  Measured (tools/gemm_trace.py, 96 windows): 15 us per tile either way - the 512 KB a tile reads and
-    // writes here move at the 35 GB/s ONE CU gets from beyond its L2 while the other CUs run their main loops, whatever the
-    // order of the requests; moving the add into the following LayerNorm launch would cost that launch more (it runs at HBM
-    // rate on every CU: + 1.1 GB per launch at 96 windows = 0.18 ms against 0.11 ms saved here).
-    auto row_ptr = [&](int r, int i) -> float* {
-      int64_t m = m0 + (wave >> 2) * 128 + r * 64 + (wave & 3) * 16 + i;
-      if (m > p.M - 1) m = p.M - 1;                 // unconditional loads (clamped row), masked stores
-      int64_t bb = 0, rr = m;
-      if (p.rows_per_batch < p.M) { const unsigned q = (unsigned)m / (unsigned)p.rows_per_batch; bb = q; rr = m - (int64_t)q * p.rows_per_batch; }
-      return outf + bb * p.c_batch_stride + rr * p.ldc + n0 + lane * 4;
-    };
-    auto raw_barrier = [&]() {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    auto to_lds = [&](int r) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = wm * 64 + q * 16 + fr;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int chunk = (wn * 16 + fq * 4 + ni) ^ (row & 15);
-          f32x4 v4 = acc[4 * r + q][ni];
-          v4.x += bias[4 * ni]; v4.y += bias[4 * ni + 1]; v4.z += bias[4 * ni + 2]; v4.w += bias[4 * ni + 3];
-          *(f32x4*)(smem + row * 1024 + chunk * 16) = v4;
-        }
+  unsigned d = blockIdx.x;
+  tile_setup(d);
+  issue_tile(0);
+#pragma unroll 1
+  for (;;) {
+#ifdef OHW_TRACE
+    unsigned g2_slot = G2_TRACE_CAP;
+    if (tid == 0) {
+      g2_slot = atomicAdd(&g2_trace_n, 1u);
+      if (g2_slot < G2_TRACE_CAP) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g2_trace_buf[g2_slot * 12 + 0] = d;
+        g2_trace_buf[g2_slot * 12 + 1] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
       }
+    }
+    G2T(2);
+#endif
+    // this tile's place (tile_setup's m0 / n0 move on to the NEXT tile inside the epilogue)
+    const int64_t m0c = m0, n0c = n0;
+    // the lane's 16 bias values, requested before the main loop (four 16-byte loads): at the head of the epilogue they were 16 branchy
+    // dword loads and a full memory round trip in every tile (gemm_trace: stores issued 4.2 us after the last MFMA)
+    const int64_t nb = n0c + wn * 64 + fq * 16;
+    f32x4 bias4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bias4[j] = *(const f32x4*)(p.bias + nb + 4 * j);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (wm == 0) {
+      // group 0: interval 2P reads phase P, interval 2P+1 computes it
+      for (int P = 0; P < NP; ++P) {
+        open_even(P);
+#ifdef OHW_TRACE
+        if (P == 0) G2T(3);
+#endif
+        read_frags(P);
+        if ((P & 1) == 0 && (P >> 1) + 1 < KT) issue_tile((P >> 1) + 1);   // the other stage: its readers are behind the barrier above
+        __builtin_amdgcn_sched_barrier(0);
+        open_odd();
+        compute();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      open_even(NP);   // the partner group's last compute interval
+    } else {
+      // group 1: one interval behind: interval 2P+1 reads phase P, interval 2P+2 computes it
+      open_even(0);
+      for (int P = 0; P < NP; ++P) {
+        open_odd();
+        read_frags(P);
+        if ((P & 1) == 0 && (P >> 1) + 1 < KT) issue_tile((P >> 1) + 1);   // this wave's share, one interval after the partner group's
+        __builtin_amdgcn_sched_barrier(0);
+        open_even(P + 1);
+        compute();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    G2T(4);
+
+    // Every fragment read of this tile lies behind the barrier both groups passed last (open_even(NP)): both stages are free.  The
+    // next tile's first K-tile is requested INSIDE this tile's epilogue, as soon as the epilogue no longer needs stage 0's 64 KiB -
+    // its 1.4 us of first bytes and the 0.9 us a fresh workgroup takes to arrive (tools/gemm_trace.py) pass under the stores.
+    const unsigned dn = d + G;
+    const bool more = dn < nwg;
+    auto prefetch_next = [&]() {
+      if (more) { tile_setup(dn); issue_tile(0); }
     };
-    auto finish = [&](int r, f32x4 (&old)[16]) {
+
+    // ---- epilogue: lane (fq, fr) holds, for each mi, columns n0 + wn*64 + fq_e*16 + [0,16) of row m ----
+    // (its addresses are built on an opaque copy of the lane id: what is invariant across the tiles of a workgroup would
+    // otherwise be hoisted out of the tile loop and parked in registers through every main loop - the kernel spilled)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int fr_e = lane_e & 15, fq_e = lane_e >> 4;
+    float bias[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bias[j] = bias4[j >> 2][j & 3];
+    bool stored = false;
+    if constexpr (EPI == EPI_BIAS_RESID_F32) {
+      // fp32 residual read-modify-write through LDS.  In the MFMA layout a lane owns 64 B of a row and a wave-instruction
+      // touches 16 rows x 4 x 16 B: 32 half-used cache lines per instruction - a tile's 512 KB of residual traffic took
+      // ~35 us that way (the K = 1280 out-projection ran at half the rate of the same shape with a 16-bit store).  The
+      // finished tile goes to the (now free) LDS, 128 rows at a time, chunk-swizzled by row, and every wave then walks
+      // whole rows: 64 lanes x 16 B = one 1-KiB row of the tile = 8 full lines per instruction.
+      float* outf = (float*)p.out;
+      // Two rounds; in round r EVERY wave sends its accumulator rows mi = 4r .. 4r + 3 to LDS (local row wm * 64 + q * 16 + fr_e of 128,
+      // 1 KiB each), then wave w walks local rows w * 16 + [0, 16) whole: tile row (w >> 2) * 128 + r * 64 + (w & 3) * 16 + i.
+      // The old values of a round's 16 rows are requested in ONE go - round 0's before the tile goes to LDS, round 1's as soon as
+      // round 0's accumulator registers are free - behind raw barriers that leave them in flight (a __syncthreads drains every
+      // outstanding load).  Measured (tools/gemm_trace.py, 96 windows): 15 us per tile either way - the 512 KB a tile reads and
+      // writes here move at the 35 GB/s ONE CU gets from beyond its L2 while the other CUs run their main loops, whatever the
+      // order of the requests; moving the add into the following LayerNorm launch would cost that launch more (it runs at HBM
+      // rate on every CU: + 1.1 GB per launch at 96 windows = 0.18 ms against 0.11 ms saved here).
+      auto row_ptr = [&](int r, int i) -> float* {
+        int64_t m = m0c + (wave >> 2) * 128 + r * 64 + (wave & 3) * 16 + i;
+        if (m > p.M - 1) m = p.M - 1;                 // unconditional loads (clamped row), masked stores
+        int64_t bb = 0, rr = m;
+        if (p.rows_per_batch < p.M) { const unsigned q = (unsigned)m / (unsigned)p.rows_per_batch; bb = q; rr = m - (int64_t)q * p.rows_per_batch; }
+        return outf + bb * p.c_batch_stride + rr * p.ldc + n0c + lane_e * 4;
+      };
+      auto to_lds = [&](int r) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = wm * 64 + q * 16 + fr_e;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const int chunk = (wn * 16 + fq_e * 4 + ni) ^ (row & 15);
+            f32x4 v4 = acc[4 * r + q][ni];
+            v4.x += bias[4 * ni]; v4.y += bias[4 * ni + 1]; v4.z += bias[4 * ni + 2]; v4.w += bias[4 * ni + 3];
+            *(f32x4*)(smem + row * 1024 + chunk * 16) = v4;
+          }
+        }
+      };
+      f32x4 old0[16], old1[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) old0[i] = *(const f32x4*)row_ptr(0, i);
+      G2T(6);
+      to_lds(0);
+      raw_barrier();
+      G2T(7);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) old1[i] = *(const f32x4*)row_ptr(1, i);      // into the registers acc[0..3] no longer need
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int lr = wave * 16 + i;
-        if (m0 + (wave >> 2) * 128 + r * 64 + (wave & 3) * 16 + i >= p.M) continue;
-        const f32x4 v4 = *(const f32x4*)(smem + lr * 1024 + ((lane ^ (lr & 15)) << 4));
-        f32x4 o4 = old[i];
+        if (m0c + (wave >> 2) * 128 + (wave & 3) * 16 + i >= p.M) continue;
+        const f32x4 v4 = *(const f32x4*)(smem + lr * 1024 + ((lane_e ^ (lr & 15)) << 4));
+        f32x4 o4 = old0[i];
         o4.x += v4.x; o4.y += v4.y; o4.z += v4.z; o4.w += v4.w;
-        *(f32x4*)row_ptr(r, i) = o4;
+        *(f32x4*)row_ptr(0, i) = o4;
       }
-    };
-    f32x4 old0[16], old1[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) old0[i] = *(const f32x4*)row_ptr(0, i);
-    G2T(6);
-    raw_barrier();                         // every wave is past its last fragment read; no DMA is outstanding
-    to_lds(0);
-    raw_barrier();
-    G2T(7);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) old1[i] = *(const f32x4*)row_ptr(1, i);      // into the registers acc[0..3] no longer need
-    finish(0, old0);
-    G2T(8);
-    raw_barrier();                         // round 0 has been read out of LDS
-    to_lds(1);
-    raw_barrier();
-    G2T(9);
-    finish(1, old1);
-    G2T(10);
-    G2T(11);
-#ifdef OHW_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    G2T(5);
-#endif
-    return;
-  }
-  if constexpr (EPI == EPI_BIAS_T || EPI == EPI_BIAS_GELU_T) {
-    if (p.lds_store) {
-      // 16-bit row-major output through the (now free) LDS: in the MFMA layout a store instruction writes 16 rows x 4 separate
-      // 16-byte pieces; here every instruction writes two whole 512-byte rows of the tile.  Row pitch 512 B, the 32 chunks of a
-      // row XOR-swizzled with row & 15 (conflict-free both ways).
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();            // every wave is past its last fragment read; no DMA is outstanding
-      __builtin_amdgcn_sched_barrier(0);
+      G2T(8);
+      raw_barrier();                         // round 0 has been read out of LDS
+      to_lds(1);
+      raw_barrier();
       G2T(9);
+      // round 1: LDS -> registers (the accumulator's are all free now), then the LDS belongs to the next tile
+      f32x4 v1[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int lr = wave * 16 + i;
+        v1[i] = *(const f32x4*)(smem + lr * 1024 + ((lane_e ^ (lr & 15)) << 4));
+      }
+      if (more) {
+        raw_barrier();
+        prefetch_next();
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (m0c + (wave >> 2) * 128 + 64 + (wave & 3) * 16 + i >= p.M) continue;
+        f32x4 o4 = old1[i];
+        o4.x += v1[i].x; o4.y += v1[i].y; o4.z += v1[i].z; o4.w += v1[i].w;
+        *(f32x4*)row_ptr(1, i) = o4;
+      }
+      G2T(10);
+      G2T(11);
+      stored = true;
+    }
+    if constexpr (EPI == EPI_BIAS_T || EPI == EPI_BIAS_GELU_T) {
+      {
+        // 16-bit row-major output through the (now free) LDS: in the MFMA layout a store instruction writes 16 rows x 4 separate
+        // 16-byte pieces; here every instruction writes two whole 512-byte rows of the tile.  Row pitch 512 B, the 32 chunks of a
+        // row XOR-swizzled with row & 15 (conflict-free both ways).
+        G2T(9);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          const int row = wm * 128 + mi * 16 + fr_e;
+          float v[16];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[ni * 4 + j] = acc[mi][ni][j] + bias[ni * 4 + j];
+          if constexpr (EPI == EPI_BIAS_GELU_T) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
+          }
+          u32x4 lo, hi;
+          lo.x = pack2<T>(v[0], v[1]); lo.y = pack2<T>(v[2], v[3]); lo.z = pack2<T>(v[4], v[5]); lo.w = pack2<T>(v[6], v[7]);
+          hi.x = pack2<T>(v[8], v[9]); hi.y = pack2<T>(v[10], v[11]); hi.z = pack2<T>(v[12], v[13]); hi.w = pack2<T>(v[14], v[15]);
+          const int c0 = wn * 8 + fq_e * 2;
+          *(u32x4*)(smem + row * 512 + ((c0 ^ fr_e) << 4)) = lo;
+          *(u32x4*)(smem + row * 512 + (((c0 + 1) ^ fr_e) << 4)) = hi;
+        }
+        G2T(7);
+        raw_barrier();
+        G2T(8);
+        T* outp = (T*)p.out;
+        // rows 0 .. 127 (stage 0's 64 KiB) first; then that half of the LDS takes the next tile's first K-tile while rows 128 .. 255 leave
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int r = half * 128 + wave * 16 + 2 * i + (lane_e >> 5);
+            const int64_t m = m0c + r;
+            if (m >= p.M) continue;
+            int64_t bb = 0, rr = m;
+            if (p.rows_per_batch < p.M) { const unsigned q = (unsigned)m / (unsigned)p.rows_per_batch; bb = q; rr = m - (int64_t)q * p.rows_per_batch; }
+            const u32x4 d4 = *(const u32x4*)(smem + r * 512 + (((lane_e & 31) ^ (r & 15)) << 4));
+            *(u32x4*)(outp + bb * p.c_batch_stride + rr * p.ldc + n0c + (lane_e & 31) * 8) = d4;
+          }
+          if (half == 0 && more) {
+            raw_barrier();
+            prefetch_next();
+          }
+        }
+        stored = true;
+      }
+    }
+    if (!stored) {
+      prefetch_next();                       // no LDS in this epilogue: the whole of it covers the next tile's first bytes
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) {
-        const int row = wm * 128 + mi * 16 + fr;
+        const int64_t m = m0c + wm * 128 + mi * 16 + fr_e;
+        if (m >= p.M) continue;
         float v[16];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[ni * 4 + j] = acc[mi][ni][j] + bias[ni * 4 + j];
-        if constexpr (EPI == EPI_BIAS_GELU_T) {
-#pragma unroll
-          for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
-        }
-        u32x4 lo, hi;
-        lo.x = pack2<T>(v[0], v[1]); lo.y = pack2<T>(v[2], v[3]); lo.z = pack2<T>(v[4], v[5]); lo.w = pack2<T>(v[6], v[7]);
-        hi.x = pack2<T>(v[8], v[9]); hi.y = pack2<T>(v[10], v[11]); hi.z = pack2<T>(v[12], v[13]); hi.w = pack2<T>(v[14], v[15]);
-        const int c0 = wn * 8 + fq * 2;
-        *(u32x4*)(smem + row * 512 + ((c0 ^ fr) << 4)) = lo;
-        *(u32x4*)(smem + row * 512 + (((c0 + 1) ^ fr) << 4)) = hi;
+        gemm_store_row<T, EPI>(p, m, n0c + wn * 64 + fq_e * 16, v);
       }
-      G2T(7);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      G2T(8);
-      T* outp = (T*)p.out;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = wave * 32 + 2 * i + (lane >> 5);
-        const int64_t m = m0 + r;
-        if (m >= p.M) continue;
-        int64_t bb = 0, rr = m;
-        if (p.rows_per_batch < p.M) { const unsigned q = (unsigned)m / (unsigned)p.rows_per_batch; bb = q; rr = m - (int64_t)q * p.rows_per_batch; }
-        const u32x4 d4 = *(const u32x4*)(smem + r * 512 + (((lane & 31) ^ (r & 15)) << 4));
-        *(u32x4*)(outp + bb * p.c_batch_stride + rr * p.ldc + n0 + (lane & 31) * 8) = d4;
-      }
-#ifdef OHW_TRACE
-      G2T(6);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      G2T(5);
-#endif
-      return;
     }
-  }
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
-    const int64_t m = m0 + wm * 128 + mi * 16 + fr;
-    if (m >= p.M) continue;
-    float v[16];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[ni * 4 + j] = acc[mi][ni][j] + bias[ni * 4 + j];
-    gemm_store_row<T, EPI>(p, m, nb, v);
-  }
 #ifdef OHW_TRACE
-  G2T(6);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  G2T(5);
+    G2T(6 + (EPI == EPI_BIAS_RESID_F32 ? 5 : 0));
+    if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G2T(5);
 #endif
+    if (!more) break;
+    d = dn;
+  }
 }
 
 template <typename T, int EPI>
@@ -370,10 +410,18 @@ static void launch256_one(const GemmParams& p, hipStream_t stream) {
   ensure_dynamic_lds((const void*)gemm256_kernel<T, EPI>, 2 * G2_STAGE);
   GemmParams q = p;
   static const int gm_env = [] { const char* e = getenv("OHW_GEMM_GM"); return e ? atoi(e) : 0; }();
-  static const int lds_store_env = [] { const char* e = getenv("OHW_GEMM_LDS_STORE"); return e ? atoi(e) : 1; }();
-  q.lds_store = lds_store_env;
   q.group_m = gm_env > 0 ? gm_env : 6;   // 6: 1 % faster than 8 at 32 and at 96 windows per pass (round 2 sweep: 4, 6, 8, 16)
-  hipLaunchKernelGGL((gemm256_kernel<T, EPI>), dim3(nwg), dim3(G2_THREADS), 2 * G2_STAGE, stream, q);
+  // OHW_GEMM_PERSIST=1: the persistent form (a workgroup per CU walks tiles d, d + G, ...; K-tile count even: a tile's first K-tile
+  // then always lands in stage 0, the stage its predecessor's epilogue frees first).  Measured, round 3 (tools/gemm_trace.py,
+  // tools/gemm_probe.py, interleaved runs, 96 windows): the first bytes arrive 0.24 instead of 1.4 us after a tile begins and the
+  // 0.9 us of dispatch are gone, but the launch is no faster at K = 1280 (1 215 against 1 217 - 1 228 us for N = 3840) and 6 %
+  // SLOWER at K = 5120: tile times differ by +- 4 % between CUs, the dispatcher gives the faster CUs more tiles and a static
+  // stride cannot; the epilogue grows by the next tile's address arithmetic and one barrier.  Off.
+  static const int persist_env = [] { const char* e = getenv("OHW_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
+  static const int n_cu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  unsigned grid = nwg;
+  if (persist_env && ((p.K / G2_BK) & 1) == 0) grid = std::min(nwg, (unsigned)std::max(8, n_cu / 8 * 8));
+  hipLaunchKernelGGL((gemm256_kernel<T, EPI>), dim3(grid), dim3(G2_THREADS), 2 * G2_STAGE, stream, q);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -382,6 +430,11 @@ void launch_gemm256(const GemmParams& p, int epilogue, hipStream_t stream) {
   if (p.M <= 0) return;
   if (p.N % G2_BN != 0 || p.K % G2_BK != 0 || p.lda % 8 != 0 || p.a_batch_stride % 8 != 0 || p.rows_per_batch <= 0 || p.M >= ((int64_t)1 << 31) || p.N >= ((int64_t)1 << 31))
     throw Error(OHW_E_INVALID_ARG, "gemm256: N must be a multiple of 256, K of 64, row strides of 8 elements");
+  {  // the kernel addresses its operands by 32-bit byte offsets
+    const int64_t nb_ = (p.M + p.rows_per_batch - 1) / p.rows_per_batch;
+    const int64_t a_bytes = ((nb_ - 1) * p.a_batch_stride + (std::min(p.M, p.rows_per_batch) + 2) * p.lda + p.K) * 2, w_bytes = p.N * p.K * 2;
+    if (a_bytes >= ((int64_t)1 << 32) || w_bytes >= ((int64_t)1 << 32)) throw Error(OHW_E_INVALID_ARG, "gemm256: an operand spans 4 GiB or more");
+  }
   switch (epilogue) {
     case EPI_BIAS_T: launch256_one<T, EPI_BIAS_T>(p, stream); break;
     case EPI_BIAS_GELU_T: launch256_one<T, EPI_BIAS_GELU_T>(p, stream); break;

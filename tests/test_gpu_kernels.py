@@ -58,6 +58,65 @@ def test_gemm_epilogues(E, dt, M, N, K):
     assert (acc - (res + ref)).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
 
 
+def _check_gemm_all_epilogues(E, dt, M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N + K)
+    td = _tdtype(E, dt)
+    A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(td)
+    W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(td)
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = A.float() @ W.float().T + bias
+    s = torch.cuda.current_stream().cuda_stream
+    L = E.lib()
+    out = torch.zeros(M, N, device="cuda")
+    assert L.ohw_dbg_gemm(dt, A.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, E.EPI_F32, s) == 0, E.last_error()
+    torch.cuda.synchronize()
+    assert (out - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+    for epi, fn in ((E.EPI_BIAS_T, lambda x: x), (E.EPI_BIAS_GELU_T, lambda x: torch.nn.functional.gelu(x))):
+        o16 = torch.zeros(M + 3, N, device="cuda", dtype=td)          # three guard rows behind the last one
+        assert L.ohw_dbg_gemm(dt, A.data_ptr(), W.data_ptr(), bias.data_ptr(), o16.data_ptr(), M, N, K, epi, s) == 0, E.last_error()
+        torch.cuda.synchronize()
+        want = fn(ref)
+        tol = (2 ** -7 if dt == 0 else 2 ** -10) * max(1.0, want.abs().max().item())
+        assert (o16[:M].float() - want).abs().max().item() <= tol
+        assert not o16[M:].any()                                       # the ragged last tile wrote nothing past row M - 1
+    res = torch.randn(M + 3, N, device="cuda", generator=g)
+    acc = res.clone()
+    assert L.ohw_dbg_gemm(dt, A.data_ptr(), W.data_ptr(), bias.data_ptr(), acc.data_ptr(), M, N, K, E.EPI_BIAS_RESID_F32, s) == 0
+    torch.cuda.synchronize()
+    assert (acc[:M] - (res[:M] + ref)).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+    assert torch.equal(acc[M:], res[M:])
+
+
+GEMM256_SHAPES = [(8200, 1280, 1280), (33000, 256, 192), (16500, 512, 128)]   # at least 128 tiles of 256 x 256: gemm256_kernel; ragged M; 20 / 3 / 2 K-tiles
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("M,N,K", GEMM256_SHAPES)
+def test_gemm256_epilogues_and_ragged_last_tile(E, dt, M, N, K):
+    """the 256 x 256 kernel by itself (test_gemm_epilogues' shapes stay below its 128-tile threshold): every epilogue against
+    torch fp32, a last m-tile that is only partly inside M, an odd K-tile count"""
+    _check_gemm_all_epilogues(E, dt, M, N, K)
+
+
+def test_gemm256_persistent_tile_loop_in_a_child_process():
+    """OHW_GEMM_PERSIST=1 (read once per process): a workgroup per CU walks its tiles and requests the next tile's first K-tile inside
+    the epilogue; same checks, one child process"""
+    import os
+    import subprocess
+    import sys
+    code = ("import torch, sys; sys.path.insert(0, %r)\n"
+            "from openhush_amd import engine as E\n"
+            "import tests.test_gpu_kernels as t\n"
+            "for dt in (0, 1):\n"
+            "    for (M, N, K) in t.GEMM256_SHAPES + [(70000, 1280, 128)]:\n"
+            "        t._check_gemm_all_epilogues(E, dt, M, N, K)\n"
+            "print('persistent ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OHW_GEMM_PERSIST="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "persistent ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_gemm_rejects_bad_shapes(E):
     a = torch.zeros(16, 64, device="cuda", dtype=torch.bfloat16)
     assert E.lib().ohw_dbg_gemm(0, a.data_ptr(), a.data_ptr(), None, a.data_ptr(), 16, 100, 64, E.EPI_BIAS_T, None) == E.OHW_E_INVALID_ARG
