@@ -649,6 +649,9 @@ __global__ __launch_bounds__(64) void self_attn_kernel(const T* __restrict__ q, 
   for (int c0 = 0; c0 < n_keys; c0 += 64) {
     const int nk = n_keys - c0 < 64 ? n_keys - c0 : 64;
     const int jk = lane < nk ? c0 + lane : c0;          // clamped: unconditional loads
+    // SLOTS: ONE table load per lane and chunk (its own key's row); the V loads take key j's row from lane j's register
+    // (v_readlane) - round 2 loaded the table 64 more times through the scalar cache, a wait each (6.8 us per launch
+    // against 2.9 without the table, profiles/r03_streaming_beam5_graphs_on_kernel_stats.csv)
     const int sk = SLOTS ? slots[jk] : b;
     vec8_t<T> kr[8];
     const vec8_t<T>* kp = (const vec8_t<T>*)(kb + sk * row_stride + ((int64_t)jk << 6));
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(64) void self_attn_kernel(const T* __restrict__ q, 
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
       const int jj = j < nk ? c0 + j : c0;
-      const int sv = SLOTS ? slots[jj] : b;
+      const int sv = SLOTS ? __builtin_amdgcn_readlane(sk, j < nk ? j : 0) : b;
       vr[j] = vb[sv * row_stride + ((int64_t)jj << 6) + lane];
     }
     __syncthreads();   // qs (first chunk) / ps of the previous chunk consumed
@@ -1018,6 +1021,27 @@ __device__ __forceinline__ bool sp_allowed(const SamplerParams& p, const SampSta
   return true;
 }
 
+// the last timestamp token among the n_cur tokens sampled so far (or -1): every thread looks at its share of the history and the
+// workgroup keeps the latest hit - ONE memory round trip.  (Each thread walking the history backwards by itself paid a dependent
+// round trip per token: 20 us of the sampler's launch and 40 us of the beam top-k's once a window had 50 tokens and no timestamp.)
+template <int NTHREADS>
+__device__ __forceinline__ int block_last_timestamp(const int32_t* toks, int n_cur, int ts_begin, int tid, int* sh /* [NTHREADS / 64] */) {
+  int key = -1;                                     // (position << 16) | token: positions < 2^9, tokens < 2^16
+  for (int i = tid; i < n_cur; i += NTHREADS) {
+    const int t = toks[i];
+    if (t >= ts_begin) key = (i << 16) | t;         // a thread's positions ascend: the last hit stays
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int ok = __shfl_xor(key, o, 64); key = ok > key ? ok : key; }
+  if ((tid & 63) == 0) sh[tid >> 6] = key;
+  __syncthreads();
+  int r = sh[0];
+#pragma unroll
+  for (int k = 1; k < NTHREADS / 64; ++k) r = sh[k] > r ? sh[k] : r;
+  __syncthreads();
+  return r >= 0 ? (r & 0xffff) : -1;
+}
+
 struct SampAcc {
   float m, s_all, s_ts;     // online log-sum-exp state: sums are relative to m
   float tv; int ti;         // best text token  (value, index)
@@ -1058,8 +1082,8 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_kernel(SamplerParams p) {
   st.is_initial = n_cur == 0;
   st.last_ts = n_cur > 0 && toks[n_cur - 1] >= p.ts_begin;
   st.penult_ts = n_cur < 2 || toks[n_cur - 2] >= p.ts_begin;
-  st.last_seen = -1;
-  for (int i = n_cur - 1; i >= 0; --i) if (toks[i] >= p.ts_begin) { st.last_seen = toks[i]; break; }
+  __shared__ int sh_ts[SP_THREADS / 64];
+  st.last_seen = block_last_timestamp<SP_THREADS>(toks, n_cur, p.ts_begin, tid, sh_ts);
   st.suppress_eot = p.force_len > 0 && n_cur < p.force_len;
   const int per = (p.n_vocab + SAMPLER_SPLIT - 1) / SAMPLER_SPLIT;
   const int lo = part * per, V = lo + per < p.n_vocab ? lo + per : p.n_vocab;
@@ -1198,21 +1222,26 @@ void launch_sampler(const SamplerParams& p, hipStream_t s) {
 // Rows: beam j of window w is decoder row w * K + j; the K rows of a window share its cross K/V (cross_attn_rows_kernel)
 // and share their common past through the kv_slot table of self_attn_kernel instead of copying K/V.
 // ------------------------------------------------------------------------------------------------
-constexpr int BEAM_THREADS = 1024;
-constexpr int BEAM_PER_THREAD = 52;     // 1024 * 52 >= 51866
+constexpr int BEAM_THREADS = 256;
+constexpr int BEAM_PER_THREAD = 26;     // 8 slices x 256 threads x 26 >= 51866
 
-// one workgroup per row: masked log-softmax of the row, then its K + 1 best tokens (ties: lowest index)
+// BEAM_SPLIT workgroups per row (round 2: one workgroup of 1024 threads per row, 78 us per launch at 5 rows): a slice computes the
+// masked soft-max state of its part of the row and its K + 1 best text and K + 1 best timestamp tokens (ties: lowest index),
+// publishes them and takes a ticket; the last arriver merges the slices in slice order, applies the timestamp-mass rule and keeps
+// the K + 1 best of what is left - the same candidates as one pass over the whole row gives (a token among the row's K + 1 best
+// of its kind is among its slice's).
 __global__ __launch_bounds__(BEAM_THREADS) void beam_topk_kernel(SamplerParams p, BeamParams bp, int first) {
   __shared__ float red_v[BEAM_THREADS / 64];
   __shared__ int red_i[BEAM_THREADS / 64];
-  __shared__ float sh_m, sh_lse, sh_tsm, sh_txt;
-  __shared__ int sh_pick;
-  const int tid = threadIdx.x;
+  __shared__ float sh_cv[2][6];
+  __shared__ int sh_ci[2][6];
+  const int tid = threadIdx.x, part = blockIdx.x;
   // the first step reads the prompt pass's logits: one row per WINDOW, candidates go to the window's beam 0
-  const int lrow = blockIdx.x;
+  const int lrow = blockIdx.y;
   const int row = first ? lrow * bp.K : lrow;
   const int w = row / bp.K;
   if (bp.win_done[w]) return;
+  const int K1 = bp.K + 1;
   const float* lg = p.logits + (int64_t)lrow * p.ld;
   const int32_t* toks = p.tokens + (int64_t)row * p.max_tokens;
   const int n_cur = bp.n_cur[w];
@@ -1220,19 +1249,19 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_topk_kernel(SamplerParams p
   st.is_initial = n_cur == 0;
   st.last_ts = n_cur > 0 && toks[n_cur - 1] >= p.ts_begin;
   st.penult_ts = n_cur < 2 || toks[n_cur - 2] >= p.ts_begin;
-  st.last_seen = -1;
-  for (int i = n_cur - 1; i >= 0; --i) if (toks[i] >= p.ts_begin) { st.last_seen = toks[i]; break; }
+  __shared__ int sh_ts[BEAM_THREADS / 64];
+  st.last_seen = block_last_timestamp<BEAM_THREADS>(toks, n_cur, p.ts_begin, tid, sh_ts);
   st.suppress_eot = 0;
+  const int per = (p.n_vocab + BEAM_SPLIT - 1) / BEAM_SPLIT;
+  const int lo = part * per, V = lo + per < p.n_vocab ? lo + per : p.n_vocab;
   float v[BEAM_PER_THREAD];
   float lmax = -INFINITY;
 #pragma unroll
   for (int u = 0; u < BEAM_PER_THREAD; ++u) {
-    const int i = tid + u * BEAM_THREADS;
-    float x = -INFINITY;
-    if (i < p.n_vocab) {
-      x = lg[i] + (p.bias ? p.bias[i] : 0.f);
-      if (!sp_allowed(p, st, i)) x = -INFINITY;
-    }
+    const int i = lo + tid + u * BEAM_THREADS;
+    float x = lg[i < V ? i : V - 1];               // unconditional loads (clamped address), masked below
+    if (p.bias) x += p.bias[i < V ? i : V - 1];
+    if (i >= V || !sp_allowed(p, st, i)) x = -INFINITY;
     v[u] = x;
     lmax = fmaxf(lmax, x);
   }
@@ -1258,7 +1287,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_topk_kernel(SamplerParams p
   float s_all = 0.f, s_ts = 0.f, t_max = -INFINITY;
 #pragma unroll
   for (int u = 0; u < BEAM_PER_THREAD; ++u) {
-    const int i = tid + u * BEAM_THREADS;
+    const int i = lo + tid + u * BEAM_THREADS;
     if (v[u] > -INFINITY) {
       const float e = expf(v[u] - m);
       s_all += e;
@@ -1266,21 +1295,110 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_topk_kernel(SamplerParams p
     }
   }
   const float sum_all = block_sum(s_all), sum_ts = block_sum(s_ts), text_max = block_max(t_max);
-  const float lse = m + logf(sum_all);
-  // the timestamp-mass rule: when the timestamps together outweigh every text token, only timestamps remain
-  const bool force_ts = !p.no_timestamps && sum_ts > 0.f && (m + logf(sum_ts) - lse) > (text_max - lse);
-  if (force_ts) {
+  // The slice's K + 1 best per kind (0: text, 1: timestamps; a slice without timestamps skips theirs): every WAVE first takes the
+  // K + 1 best of its own 64 x 26 values by itself - rounds of arg-max over registers and shuffles, a picked token struck out, no
+  // barrier - then wave 0 takes the K + 1 best of the waves' 4 x (K + 1) (a round with three barriers and a serial scan each took
+  // the kernel to 47 us)
+  __shared__ float sh_wv[2][BEAM_THREADS / 64][6];
+  __shared__ int sh_wi[2][BEAM_THREADS / 64][6];
+  const int wv = tid >> 6, ln = tid & 63;
+  for (int kind = 0; kind < 2; ++kind) {
+    const bool any = kind == 0 ? lo < p.ts_begin : V > p.ts_begin;       // uniform
+    for (int c = 0; c < K1; ++c) {
+      float bv = -INFINITY; int bi = 0x7fffffff;
+      if (any) {
 #pragma unroll
-    for (int u = 0; u < BEAM_PER_THREAD; ++u) if (tid + u * BEAM_THREADS < p.ts_begin) v[u] = -INFINITY;
-  }
-  // K + 1 rounds of arg-max; a picked token is struck out
-  for (int c = 0; c <= bp.K; ++c) {
-    float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int u = 0; u < BEAM_PER_THREAD; ++u) {
+          const int i = lo + tid + u * BEAM_THREADS;
+          const bool mine = kind == 0 ? i < p.ts_begin : i >= p.ts_begin;
+          if (mine && (v[u] > bv || (v[u] == bv && v[u] > -INFINITY && i < bi))) { bv = v[u]; bi = i; }
+        }
 #pragma unroll
-    for (int u = 0; u < BEAM_PER_THREAD; ++u) {
-      const int i = tid + u * BEAM_THREADS;
-      if (v[u] > bv || (v[u] == bv && v[u] > -INFINITY && i < bi)) { bv = v[u]; bi = i; }
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (bv > -INFINITY) {
+#pragma unroll
+          for (int u = 0; u < BEAM_PER_THREAD; ++u) if (lo + tid + u * BEAM_THREADS == bi) v[u] = -INFINITY;
+        }
+      }
+      if (ln == 0) { sh_wv[kind][wv][c] = bv; sh_wi[kind][wv][c] = bv > -INFINITY ? bi : -1; }
     }
+  }
+  __syncthreads();
+  if (wv == 0) {
+    for (int kind = 0; kind < 2; ++kind) {
+      float cv = -INFINITY; int ci = -1;
+      if (ln < (BEAM_THREADS / 64) * K1) { cv = sh_wv[kind][ln / K1][ln % K1]; ci = sh_wi[kind][ln / K1][ln % K1]; }
+      for (int c = 0; c < K1; ++c) {
+        float bv = ci >= 0 ? cv : -INFINITY; int bi = ci >= 0 ? ci : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        const bool got = bv > -INFINITY;
+        if (ln == 0) { sh_cv[kind][c] = bv; sh_ci[kind][c] = got ? bi : -1; }
+        if (got && ci == bi) { cv = -INFINITY; ci = -1; }
+      }
+    }
+  }
+  __syncthreads();
+  __shared__ int sh_last;
+  __shared__ unsigned sh_w[BEAM_SPLIT][28];
+  if (tid == 0) {
+    // publish the slice, take a ticket; only the last arriver's workgroup goes on
+    unsigned* slot = bp.part + ((int64_t)row * BEAM_SPLIT + part) * BEAM_PART_WORDS;
+    unsigned words[28];
+    words[0] = __float_as_uint(m); words[1] = __float_as_uint(sum_all); words[2] = __float_as_uint(sum_ts); words[3] = __float_as_uint(text_max);
+#pragma unroll
+    for (int kind = 0; kind < 2; ++kind)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        words[4 + (kind * 6 + c) * 2] = __float_as_uint(c < K1 ? sh_cv[kind][c] : -INFINITY);
+        words[5 + (kind * 6 + c) * 2] = (unsigned)(c < K1 ? sh_ci[kind][c] : -1);
+      }
+#pragma unroll
+    for (int k = 0; k < 28; ++k) __hip_atomic_store(slot + k, words[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(bp.tickets + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_last = ticket == BEAM_SPLIT - 1;
+    if (sh_last) __hip_atomic_store(bp.tickets + row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!sh_last) return;
+  // the last arriver: every slice's state in ONE round trip (a thread per word, agent-scope loads), then the first 96 threads
+  // hold one candidate each and K + 1 rounds of arg-max run over them
+  if (tid < BEAM_SPLIT * 28) {
+    const unsigned* all = bp.part + (int64_t)row * BEAM_SPLIT * BEAM_PART_WORDS;
+    sh_w[tid / 28][tid % 28] = __hip_atomic_load(all + (tid / 28) * BEAM_PART_WORDS + tid % 28, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  float M = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < BEAM_SPLIT; ++q) M = fmaxf(M, __uint_as_float(sh_w[q][0]));
+  float S = 0.f, Sts = 0.f, tmax = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < BEAM_SPLIT; ++q) {                  // slice order: every thread computes the same sums
+    const float mq = __uint_as_float(sh_w[q][0]);
+    const float f = mq == -INFINITY ? 0.f : expf(mq - M);
+    S += __uint_as_float(sh_w[q][1]) * f;
+    Sts += __uint_as_float(sh_w[q][2]) * f;
+    tmax = fmaxf(tmax, __uint_as_float(sh_w[q][3]));
+  }
+  const float lse = M + logf(S);
+  // the timestamp-mass rule: when the timestamps together outweigh every text token, only timestamps remain
+  const bool force_ts = !p.no_timestamps && Sts > 0.f && (M + logf(Sts) - lse) > (tmax - lse);
+  float cv = -INFINITY; int ci = -1;
+  if (tid < BEAM_SPLIT * 12) {
+    const int q = tid / 12, k = tid % 12;
+    ci = (int)sh_w[q][5 + 2 * k];
+    cv = __uint_as_float(sh_w[q][4 + 2 * k]);
+    if (ci < 0 || (force_ts && k < 6)) { cv = -INFINITY; ci = -1; }
+  }
+  for (int c = 0; c < K1; ++c) {
+    float bv = ci >= 0 ? cv : -INFINITY; int bi = ci >= 0 ? ci : 0x7fffffff;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
@@ -1288,20 +1406,16 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_topk_kernel(SamplerParams p
     }
     if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
     __syncthreads();
+    float rv = red_v[0]; int ri = red_i[0];
+    for (int k = 1; k < BEAM_THREADS / 64; ++k) if (red_v[k] > rv || (red_v[k] == rv && red_i[k] < ri)) { rv = red_v[k]; ri = red_i[k]; }
+    __syncthreads();
+    const bool got = rv > -INFINITY;
     if (tid == 0) {
-      float rv = red_v[0]; int ri = red_i[0];
-      for (int k = 1; k < BEAM_THREADS / 64; ++k) if (red_v[k] > rv || (red_v[k] == rv && red_i[k] < ri)) { rv = red_v[k]; ri = red_i[k]; }
-      bp.cand_lp[(int64_t)row * (bp.K + 1) + c] = rv > -INFINITY ? rv - lse : -INFINITY;
-      bp.cand_tok[(int64_t)row * (bp.K + 1) + c] = rv > -INFINITY ? ri : -1;
-      sh_pick = rv > -INFINITY ? ri : -1;
+      bp.cand_lp[(int64_t)row * K1 + c] = got ? rv - lse : -INFINITY;
+      bp.cand_tok[(int64_t)row * K1 + c] = got ? ri : -1;
     }
-    __syncthreads();
-    const int pick = sh_pick;
-#pragma unroll
-    for (int u = 0; u < BEAM_PER_THREAD; ++u) if (tid + u * BEAM_THREADS == pick) v[u] = -INFINITY;
-    __syncthreads();
+    if (got && ci == ri) { cv = -INFINITY; ci = -1; }        // struck out (an index appears once: the slices are disjoint)
   }
-  (void)sh_m; (void)sh_lse; (void)sh_tsm; (void)sh_txt;
 }
 
 // one workgroup per window: rank the candidates, retire finished sequences, reorder the beams
@@ -1314,33 +1428,43 @@ __global__ __launch_bounds__(256) void beam_update_kernel(SamplerParams p, BeamP
   if (bp.win_done[w]) return;
   const int n_cur = bp.n_cur[w];
   const int P = bp.n_past_w[w];          // position the step that just ran wrote (prompt pass: n_prompt - 1)
+  // the window's K x (K + 1) candidates in ONE memory round trip (thread per candidate); one thread reading them in its
+  // ranking loop paid a dependent round trip per candidate (34 us per launch)
+  __shared__ int s_ctok[MAXC];
+  __shared__ float s_csc[MAXC];
+  const int nb = first ? 1 : K;          // first step: the K beams are identical - only beam 0 proposes
+  if (tid < nb * (K + 1)) {
+    const int j = tid / (K + 1), c = tid % (K + 1), r = w * K + j;
+    s_ctok[tid] = bp.cand_tok[(int64_t)r * (K + 1) + c];
+    s_csc[tid] = (first ? 0.f : bp.beam_sum[r]) + bp.cand_lp[(int64_t)r * (K + 1) + c];
+  }
+  __syncthreads();
+  // rank of a candidate = how many candidates come before it (score descending; ties: the earlier beam, then the more likely token =
+  // the lower candidate index): a thread per candidate, all reads from LDS (one thread sorting private arrays took 30 us: they
+  // live in scratch memory)
+  __shared__ int s_ord[MAXC];
+  const int n_all = nb * (K + 1);
+  if (tid < MAXC) s_ord[tid] = -1;
+  __syncthreads();
+  if (tid < n_all && s_ctok[tid] >= 0) {
+    int rank = 0;
+    const float mine = s_csc[tid];
+    for (int o = 0; o < n_all; ++o)
+      if (s_ctok[o] >= 0 && (s_csc[o] > mine || (s_csc[o] == mine && o < tid))) ++rank;
+    s_ord[rank] = tid;
+  }
+  __syncthreads();
   if (tid == 0) {
-    float sc[MAXC]; int src[MAXC], tok[MAXC], ord[MAXC];
-    int nc = 0;
-    const int nb = first ? 1 : K;        // first step: the K beams are identical - only beam 0 proposes
-    for (int j = 0; j < nb; ++j) {
-      const int r = w * K + j;
-      for (int c = 0; c <= K; ++c) {
-        const int t = bp.cand_tok[(int64_t)r * (K + 1) + c];
-        if (t < 0) continue;
-        sc[nc] = (first ? 0.f : bp.beam_sum[r]) + bp.cand_lp[(int64_t)r * (K + 1) + c];
-        src[nc] = j; tok[nc] = t; ord[nc] = nc; ++nc;
-      }
-    }
-    // stable insertion sort by score, descending (ties: the earlier beam, then the more likely token)
-    for (int a = 1; a < nc; ++a) {
-      const int o = ord[a]; int b2 = a - 1;
-      while (b2 >= 0 && sc[ord[b2]] < sc[o]) { ord[b2 + 1] = ord[b2]; --b2; }
-      ord[b2 + 1] = o;
-    }
     int saved = 0, nfin = 0, fin_cnt = bp.fin_cnt[w];
-    for (int a = 0; a < nc && saved < K; ++a) {
-      const int o = ord[a];
-      if (tok[o] == p.eot) {
+    for (int a = 0; a < n_all && saved < K; ++a) {
+      const int o = s_ord[a];
+      if (o < 0) break;                    // ranks are dense: the first gap ends the list
+      const int src_o = o / (K + 1);
+      if (s_ctok[o] == p.eot) {
         // newly finished, best first; the pool takes them while it has room (max_candidates = beam size)
-        if (fin_cnt < K) { s_fin_src[nfin] = src[o]; s_fin_sum[nfin] = sc[o]; s_fin_slot[nfin] = fin_cnt; ++nfin; ++fin_cnt; }
+        if (fin_cnt < K) { s_fin_src[nfin] = src_o; s_fin_sum[nfin] = s_csc[o]; s_fin_slot[nfin] = fin_cnt; ++nfin; ++fin_cnt; }
       } else {
-        s_src[saved] = src[o]; s_tok[saved] = tok[o]; s_sum[saved] = sc[o]; ++saved;
+        s_src[saved] = src_o; s_tok[saved] = s_ctok[o]; s_sum[saved] = s_csc[o]; ++saved;
       }
     }
     // fewer live continuations than beams (everything else was end-of-text or forbidden): repeat the last one
@@ -1352,29 +1476,29 @@ __global__ __launch_bounds__(256) void beam_update_kernel(SamplerParams p, BeamP
     s_done = (full || out_of_room) ? 1 : 0;
   }
   __syncthreads();
-  // finished sequences: the source beam's tokens (end-of-text itself is not stored)
-  for (int f = 0; f < s_nfin; ++f) {
-    const int32_t* from = p.tokens + (int64_t)(w * K + s_fin_src[f]) * p.max_tokens;
-    int32_t* to = bp.fin_tok + ((int64_t)w * K + s_fin_slot[f]) * p.max_tokens;
-    for (int i = tid; i < n_cur; i += 256) to[i] = from[i];
-    if (tid == 0) { bp.fin_len[w * K + s_fin_slot[f]] = n_cur; bp.fin_sum[w * K + s_fin_slot[f]] = s_fin_sum[f]; }
+  // finished sequences: the source beam's tokens (end-of-text itself is not stored); one flat index over (sequence, position)
+  // so that every copy of the launch is ONE round trip (a loop over the sequences was a dependent round trip each)
+  for (int idx = tid; idx < s_nfin * n_cur; idx += 256) {
+    const int f = idx / n_cur, i = idx - f * n_cur;
+    bp.fin_tok[((int64_t)w * K + s_fin_slot[f]) * p.max_tokens + i] = p.tokens[(int64_t)(w * K + s_fin_src[f]) * p.max_tokens + i];
   }
+  if (tid < s_nfin) { bp.fin_len[w * K + s_fin_slot[tid]] = n_cur; bp.fin_sum[w * K + s_fin_slot[tid]] = s_fin_sum[tid]; }
   // new beams: history and kv_slot rows are gathered from the source beams into the other half of the double buffers
-  for (int j = 0; j < K; ++j) {
-    const int r = w * K + j, rs = w * K + s_src[j];
-    const int32_t* from = p.tokens + (int64_t)rs * p.max_tokens;
-    int32_t* to = bp.tokens_next + (int64_t)r * p.max_tokens;
-    for (int i = tid; i < n_cur; i += 256) to[i] = from[i];
-    const int32_t* sf = bp.kv_slot + (int64_t)rs * p.n_text_ctx;
-    int32_t* stt = bp.kv_slot_next + (int64_t)r * p.n_text_ctx;
-    for (int i = tid; i <= P; i += 256) stt[i] = first ? w : sf[i];      // after the prompt pass every position lives in slot w
-    if (tid == 0) {
-      to[n_cur] = s_tok[j];
-      stt[P + 1] = r;                     // the next step writes position P + 1 of this beam into its own row
-      bp.beam_sum[r] = s_sum[j];
-      p.next_tok[r] = s_tok[j];
-      p.n_past[r] = P + 1;
-    }
+  for (int idx = tid; idx < K * n_cur; idx += 256) {
+    const int j = idx / n_cur, i = idx - j * n_cur;
+    bp.tokens_next[(int64_t)(w * K + j) * p.max_tokens + i] = p.tokens[(int64_t)(w * K + s_src[j]) * p.max_tokens + i];
+  }
+  for (int idx = tid; idx < K * (P + 1); idx += 256) {
+    const int j = idx / (P + 1), i = idx - j * (P + 1);
+    bp.kv_slot_next[(int64_t)(w * K + j) * p.n_text_ctx + i] = first ? w : bp.kv_slot[(int64_t)(w * K + s_src[j]) * p.n_text_ctx + i];   // after the prompt pass every position lives in slot w
+  }
+  if (tid < K) {
+    const int j = tid, r = w * K + j;
+    bp.tokens_next[(int64_t)r * p.max_tokens + n_cur] = s_tok[j];
+    bp.kv_slot_next[(int64_t)r * p.n_text_ctx + P + 1] = r;      // the next step writes position P + 1 of this beam into its own row
+    bp.beam_sum[r] = s_sum[j];
+    p.next_tok[r] = s_tok[j];
+    p.n_past[r] = P + 1;
   }
   if (tid == 0) {
     bp.n_cur[w] = n_cur + 1;
@@ -1385,8 +1509,9 @@ __global__ __launch_bounds__(256) void beam_update_kernel(SamplerParams p, BeamP
 
 void launch_beam_step(const SamplerParams& p, const BeamParams& bp, int n_windows, int first, hipStream_t s) {
   if (bp.K < 2 || bp.K > 5) throw Error(OHW_E_INVALID_ARG, "beam search: beam size must be in 2..5");
-  if (p.n_vocab > BEAM_THREADS * BEAM_PER_THREAD) throw Error(OHW_E_INVALID_ARG, "beam search: vocabulary too large");
-  hipLaunchKernelGGL(beam_topk_kernel, dim3(first ? n_windows : n_windows * bp.K), dim3(BEAM_THREADS), 0, s, p, bp, first);
+  if (p.n_vocab > BEAM_SPLIT * BEAM_THREADS * BEAM_PER_THREAD) throw Error(OHW_E_INVALID_ARG, "beam search: vocabulary too large");
+  if (!bp.part || !bp.tickets) throw Error(OHW_E_INVALID_ARG, "beam search: the split top-k needs its slice buffers");
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(BEAM_SPLIT, first ? n_windows : n_windows * bp.K), dim3(BEAM_THREADS), 0, s, p, bp, first);
   hipLaunchKernelGGL(beam_update_kernel, dim3(n_windows), dim3(256), 0, s, p, bp, first);
   HIP_CHECK(hipGetLastError());
 }

@@ -125,7 +125,7 @@ struct ohw_state {
   int xa_rows = 0;
   DevBuf step_tok, n_past, tokens, n_cur, next_tok, done, n_done, sum_lp;
   // beam search (made on first use): candidates, cumulative scores, the kv_slot / token-history double buffers, finished pool
-  DevBuf bm_cand_lp, bm_cand_tok, bm_sum, bm_slot[2], bm_tok2, bm_ncur, bm_npast, bm_done, bm_fin_cnt, bm_fin_tok, bm_fin_len, bm_fin_sum;
+  DevBuf bm_cand_lp, bm_cand_tok, bm_sum, bm_slot[2], bm_tok2, bm_ncur, bm_npast, bm_done, bm_fin_cnt, bm_fin_tok, bm_fin_len, bm_fin_sum, bm_part, bm_ticket;
   // one entry = the PAIR of graphs of a (windows, beam size, sampler parameters, CU budget, cross-attention variant) key: the
   // odd and the even iteration (the token-history and kv_slot double buffers alternate); made, looked up and evicted together,
   // so a call never holds an exec of an entry it then evicts
@@ -1059,6 +1059,7 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* sp, int n_windows, i
       st->bm_ncur.alloc((size_t)MB * 4, true); st->bm_npast.alloc((size_t)MB * 4, true); st->bm_done.alloc((size_t)MB * 4, true);
       st->bm_fin_cnt.alloc((size_t)MB * 4, true); st->bm_fin_tok.alloc((size_t)MB * MT * 4, true); st->bm_fin_len.alloc((size_t)MB * 4, true);
       st->bm_fin_sum.alloc((size_t)MB * 4, true);
+      st->bm_part.alloc((size_t)MB * BEAM_SPLIT * BEAM_PART_WORDS * 4, true); st->bm_ticket.alloc((size_t)MB * 4, true);
     }
     int32_t prompt[8];
     const int n_prompt = build_prompt(c, sp, prompt);
@@ -1086,6 +1087,7 @@ int ohw_beam_search(ohw_state* st, const ohw_sample_params* sp, int n_windows, i
       bp->n_cur = st->bm_ncur.as<int32_t>(); bp->n_past_w = st->bm_npast.as<int32_t>(); bp->win_done = st->bm_done.as<int32_t>();
       bp->fin_cnt = st->bm_fin_cnt.as<int32_t>(); bp->fin_tok = st->bm_fin_tok.as<int32_t>(); bp->fin_len = st->bm_fin_len.as<int32_t>();
       bp->fin_sum = st->bm_fin_sum.as<float>();
+      bp->part = st->bm_part.as<unsigned>(); bp->tickets = st->bm_ticket.as<unsigned>();
     };
     int steps = 0, last_q = 1;
     Dispatch::run(c->dtype, [&](auto* tag) {

@@ -170,7 +170,11 @@ struct BeamParams {
   int32_t* fin_tok;       // [windows][K][max_tokens]
   int32_t* fin_len;       // [windows][K]
   float* fin_sum;         // [windows][K] cumulative log-probability, the end-of-text token's included
+  unsigned* part;         // [rows][BEAM_SPLIT][BEAM_PART_WORDS] slice states of the split top-k (beam_topk_kernel)
+  unsigned* tickets;      // [rows], zero between launches (re-armed by the kernel)
 };
+constexpr int BEAM_SPLIT = 8;         // workgroups per logits row
+constexpr int BEAM_PART_WORDS = 32;   // max, sum, timestamp sum, best text logit, then (K + 1) text and (K + 1) timestamp candidates (value, index)
 void launch_beam_step(const SamplerParams& p, const BeamParams& bp, int n_windows, int first, hipStream_t s);
 constexpr int SAMPLER_SPLIT = 8;
 constexpr int SAMPLER_PART_WORDS = 12;
