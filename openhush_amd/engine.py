@@ -1028,6 +1028,15 @@ class WhisperEngine:
             _raise(rc)
         return cls(h)
 
+    @classmethod
+    def from_config(cls, config: "TranscriptionConfig", data_dir: Optional[str] = None, device: int = 0, dtype: int = OHW_DTYPE_BF16,
+                    max_batch: int = 1) -> "WhisperEngine":
+        """reference src/engine/whisper.rs:183-201: model = effective_model() parsed as a WhisperModel (anything it does not know:
+        Base), path = <data dir>/models/<filename>, use_gpu = device != "cpu" (any case), then new().  `data_dir` stands for
+        Config::data_dir() (the platform's ProjectDirs path; default here: $XDG_DATA_HOME or ~/.local/share, then /openhush)."""
+        path, use_gpu = config.engine_arguments(data_dir)
+        return cls.new(path, config.language, config.translate, use_gpu, device, dtype, max_batch)
+
     def transcribe(self, audio: AudioBuffer) -> TranscriptionResult:
         s = np.ascontiguousarray(audio.samples, dtype=np.float32)
         buf = C.create_string_buffer(256)
@@ -1217,6 +1226,35 @@ _MODEL_SIZES = {"tiny": 75_000_000, "base": 142_000_000, "small": 466_000_000, "
 def model_size_bytes(name: str) -> int:
     key = name.lower()
     return _MODEL_SIZES[_MODEL_ALIASES.get(key, key)]
+
+
+_PRESET_MODEL = {"instant": "small", "balanced": "medium", "quality": "large-v3", "custom": "base"}
+
+
+@dataclasses.dataclass
+class TranscriptionConfig:
+    """the fields of the reference's [transcription] table WhisperEngine::from_config reads (src/config.rs:662-696; defaults
+    :641, :1080-1090)"""
+    preset: str = "balanced"          # instant | balanced | quality | custom
+    model: str = "large-v3"           # only used when preset == "custom"
+    language: str = "auto"
+    device: str = "cuda"
+    translate: bool = False
+
+    def effective_model(self) -> str:
+        """src/config.rs:697-706 (known answers :1592-1622)"""
+        return self.model if self.preset == "custom" else _PRESET_MODEL[self.preset]
+
+    def engine_arguments(self, data_dir: Optional[str] = None):
+        """(model_path, use_gpu) as from_config derives them"""
+        import os
+        try:
+            fname = model_filename(self.effective_model())
+        except KeyError:
+            fname = model_filename("base")            # .parse().unwrap_or(WhisperModel::Base)
+        if data_dir is None:
+            data_dir = os.path.join(os.environ.get("XDG_DATA_HOME") or os.path.join(os.path.expanduser("~"), ".local", "share"), "openhush")
+        return os.path.join(data_dir, "models", fname), self.device.lower() != "cpu"
 
 
 def format_size(n: int) -> str:

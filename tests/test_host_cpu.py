@@ -93,6 +93,23 @@ def test_model_sizes_and_format_size():
     assert E.format_size(1024 ** 3) == "1.0 GB" and E.format_size(3_000_000_000) == "2.8 GB"
 
 
+def test_from_config_resolves_model_path_and_device(tmp_path):
+    """WhisperEngine::from_config (src/engine/whisper.rs:183-201) with the reference's own known answers for effective_model()
+    (src/config.rs:1592-1622): preset -> model, custom -> the explicit model, an unknown name -> base, device "cpu" in any case
+    -> use_gpu false; the engine call itself then reports the missing file before any device work"""
+    T = E.TranscriptionConfig
+    assert T(preset="instant").effective_model() == "small" and T(preset="balanced").effective_model() == "medium"
+    assert T(preset="quality").effective_model() == "large-v3" and T(preset="custom", model="tiny").effective_model() == "tiny"
+    assert T().effective_model() == "medium" and T().language == "auto" and T().device == "cuda"       # the defaults
+    path, gpu = T(preset="quality").engine_arguments(str(tmp_path))
+    assert path == str(tmp_path / "models" / "ggml-large-v3.bin") and gpu is True
+    path, gpu = T(preset="custom", model="no-such-model", device="CPU").engine_arguments(str(tmp_path))
+    assert path == str(tmp_path / "models" / "ggml-base.bin") and gpu is False
+    with pytest.raises(E.ModelNotFound) as ei:
+        E.WhisperEngine.from_config(T(preset="instant", language="de"), str(tmp_path))
+    assert "ggml-small.bin" in str(ei.value) and "openhush model download small" in str(ei.value)
+
+
 def test_missing_model_is_reported_before_any_device_work(tmp_path):
     # reference src/engine/whisper.rs:141-154 and test :984-997
     with pytest.raises(E.ModelNotFound) as ei:
