@@ -544,20 +544,33 @@ def pool_bench(args, torch, E, synth):
     else:
         pool.set_schedule(E.OHW_SCHEDULE_SEQUENTIAL if args.pipeline <= 0 else E.OHW_SCHEDULE_PIPELINE)
 
-    def recording(n_steps, first_id):
-        n_win = n_dev * B * n_steps
+    # ohw_pool_transcribe has ohw_engine_transcribe's contract, validate_audio included: at most 2 h per call (the reference's limit,
+    # src/engine/validation.rs:67-72) = 240 windows.  The K steps are as many calls as that takes, windows distinct throughout.
+    MAX_WIN = 240
+
+    def recording(n_win, first_id):
         out = np.empty(n_win * synth.CHUNK_SAMPLES, np.float32)
         for w in range(n_win):
             out[w * synth.CHUNK_SAMPLES:(w + 1) * synth.CHUNK_SAMPLES] = synth.synth_audio(first_id + w)
         return out
-    if args.warmup > 0:
-        pool.transcribe(E.AudioBuffer(recording(args.warmup, 0), 16000))
-    rec = recording(args.steps, 100000)
+
+    def calls(n_steps, first_id):
+        left, at, recs = n_dev * B * n_steps, first_id, []
+        while left > 0:
+            n = min(left, MAX_WIN)
+            recs.append(recording(n, at))
+            at += n; left -= n
+        return recs
+    for r in calls(args.warmup, 0):
+        pool.transcribe(E.AudioBuffer(r, 16000))
+    recs = calls(args.steps, 100000)
     torch.cuda.synchronize()
+    lens = []
     t0 = time.perf_counter()
-    pool.transcribe(E.AudioBuffer(rec, 16000))
+    for r in recs:
+        pool.transcribe(E.AudioBuffer(r, 16000))
+        lens += pool.last_window_tokens()
     dt = time.perf_counter() - t0
-    lens = pool.last_window_tokens()
     assert len(lens) == n_dev * B * args.steps and all(n == args.tokens for n in lens), "every window must decode exactly --tokens tokens"
     value = 30.0 * len(lens) / dt
     line = {
@@ -565,7 +578,7 @@ def pool_bench(args, torch, E, synth):
         "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic",
         "config": {"workload": f"--pool: ONE process, ohw_pool_transcribe over devices {devices} ({pool.broadcast_kind} weight broadcast"
-                               f"{': ' + pool.broadcast_note if pool.broadcast_note else ''}), {args.model} dims, one recording of {len(lens)} distinct 30 s windows = "
+                               f"{': ' + pool.broadcast_note if pool.broadcast_note else ''}), {args.model} dims, {len(recs)} recording(s) of at most 240 windows (2 h, the validation limit of the call), {len(lens)} distinct 30 s windows = "
                                f"{args.steps} steps of batch={B} per GPU dealt round-robin, greedy, {args.tokens} tokens/window (EOT suppressed), HOST PCM in "
                                f"(PCIe-inclusive), engine schedule {'LANES %dx%d' % (args.phases, args.merge) if args.phases > 1 else 'sequential/pipeline'}",
                    "model_dims": hp.as_list(), "pool_load_s": round(load_s, 2), "broadcast": pool.broadcast_kind},
