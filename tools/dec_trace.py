@@ -44,7 +44,13 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--layers", type=int, default=2, help="how many layers of the step to print")
     a = ap.parse_args()
-    hp = synth.PRESETS[a.model]
+    # "small:1" = the preset with ONE decoder layer (its 16.5 MB of weights stay in the L2s from token to token: what a launch costs
+    # when its weights need not come from beyond L2)
+    name, _, nl = a.model.partition(":")
+    hp = synth.PRESETS[name]
+    if nl:
+        import dataclasses
+        hp = dataclasses.replace(hp, n_text_layer=int(nl))
     ctx = E.Context.synthetic(hp.as_list(), 1234, 0, E.OHW_DTYPE_BF16 if a.dtype == "bf16" else E.OHW_DTYPE_F16)
     st = E.State(ctx, a.batch)
     pcm = torch.from_numpy(np.stack([synth.synth_audio(b) for b in range(a.batch)])).cuda()
