@@ -381,3 +381,51 @@ def test_config5_large_v3_beam5_chunk_against_oracle_and_its_properties(E, oracl
     ts = [t for t in g["tokens"] if t >= om.tok_beg]
     assert ts == sorted(ts)
     st.close(); st1.close(); st0.close(); om.close()
+
+
+def test_config5_streaming_session_at_large_v3_runs_the_whole_stage_order(E):
+    """BASELINE config #5 end to end at its own size: large-v3 dims, 5 s chunks through StreamingSession - chunk timer, noise
+    reduction (the denoise hook with a frame-halving stand-in for the RNNoise network) -> normalise / compress / limit -> VAD hook
+    -> mel + encoder + cross K/V -> beam = 5 on the two alternating step graphs -> tracker.  Every chunk must equal the same
+    preprocessed samples taken through a fresh state as one window; a silent chunk is dropped by the VAD; the second session over
+    the same audio (graphs cached) returns the same results."""
+    from openhush_amd import streaming as S
+    from openhush_amd.tracker import ChunkResult, TranscriptionTracker
+    hp = synth.PRESETS["large-v3"]
+    ctx = E.Context.synthetic(hp.as_list(), 1234, 0, E.OHW_DTYPE_BF16)
+    tok = ctx.tok
+    bias = np.zeros(hp.n_vocab, np.float32); bias[tok.timestamp_begin:] = 4.0; bias[tok.eot] = 9.0
+    p = ctx.default_params(); p.n_max = 12
+    cfg = E.default_preprocess_config(); cfg.preprocessing = 1
+    half = lambda f: (f * np.float32(0.5)).astype(np.float32)           # noqa: E731
+    n = 16000 * 5
+    rec = np.concatenate([synth.synth_audio(70)[:n], np.zeros(n, np.float32), synth.synth_audio(71)[:n], synth.synth_audio(72)[:n]])
+    vad = E.EnergyVad(-40.0)
+
+    def run():
+        ses = S.StreamingSession(ctx, beam_size=5, vad=vad, sequence_id=9, params=p, audio_config=cfg, noise_reduction=True,
+                                 noise_reduction_strength=1.0, denoiser=E.Denoiser(half))
+        ses.state.set_logit_bias(bias)               # end-of-text and timestamps win now and then: beams finish at different steps
+        out = []
+        for i in range(4):
+            out += ses.tick(rec, (i + 1) * n, is_final=(i == 3))
+        return ses, out
+    ses, out = run()
+    assert [r.chunk_id for r in out] == [0, 1, 2, 3] and ses.skipped_silent == 1 and out[1].text == ""
+    assert ses.windows_decoded == 3 and any(r.text for r in out)
+    _, again = run()
+    assert [r.text for r in again] == [r.text for r in out]
+    st = E.State(ctx, 5)
+    st.set_logit_bias(bias)
+    tr = TranscriptionTracker()
+    for i in (0, 2, 3):
+        buf = E.AudioBuffer(rec[i * n:(i + 1) * n].copy(), 16000)
+        buf.preprocess(cfg, True, 1.0, E.Denoiser(half))
+        st.mel(buf.samples[None, :], [len(buf.samples)], E.OHW_MEL_ZERO_TAIL, want=False); st.encode(1)
+        toks = st.beam_search(1, 5, p)[0]["tokens"]
+        text = b"".join(ctx.token_text(t) for t in toks if t < tok.eot).decode("utf-8", "replace").strip()
+        tr.add_result(ChunkResult(text, 9, i))
+    tr.add_result(ChunkResult("", 9, 1))                                # the chunk the VAD dropped
+    want = tr.take_ready()                                              # the tracker's overlap de-duplication applied
+    assert [r.text for r in want] == [r.text for r in out]
+    st.close()
