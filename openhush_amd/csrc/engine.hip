@@ -225,7 +225,7 @@ void state_alloc(ohw_state* st) {
   const size_t m_tiles = ((size_t)st->m_max + 31) / 32 * 32;
   st->dy.alloc(m_tiles * dt * 2, true);
   // post-norm decoder GEMMs (decode.hip): OHW_DEC_POSTNORM=1 (off by default: measured, no gain - the LayerNorm prologue
-  // already hides under the weights' first-byte latency, DESIGN.md section 5); never with a split-K knob (the split path
+  // already hides under the weights' first-byte latency, DESIGN.md Appendix A); never with a split-K knob (the split path
   // publishes no statistics); dt must be a multiple of 32
   st->graphs_enabled = env_int("OHW_GRAPHS", 1, 0, 1) != 0;      // 0: the decode iterations are launched kernel by kernel (diagnostics)
   // the greedy iteration is replayed as a hipGraph below this batch size only: a graph pays while the step is launch-bound

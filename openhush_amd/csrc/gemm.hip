@@ -12,7 +12,7 @@
 // 16-byte chunks XOR-swizzled by (row & 7) so every ds_read_b128 fragment read is conflict-free.
 // Global -> LDS goes through registers (loads of tile k+1 are issued before the MFMAs of tile k and
 // written to the other LDS stage afterwards: one barrier per K-step).
-// Roofline: MFMA-bound (arithmetic intensity = 64 flop/B at this tile; DESIGN.md section 4).
+// Roofline: MFMA-bound (arithmetic intensity = 64 flop/B at this tile; DESIGN.md section 5).
 #include "gemm.hpp"
 #include "gemm_epilogue.hpp"
 

@@ -678,7 +678,7 @@ class State:
             _check(lib().ohw_state_set_logit_bias(self.h, _fp(b), b.size))
 
     def set_persistent(self, on: bool = True):
-        """ohw_state_set_persistent: the one-launch decoder step for at most 16 single-token rows (default off: slower than the launches it replaces, DESIGN.md section 5)"""
+        """ohw_state_set_persistent: the one-launch decoder step for at most 16 single-token rows (default off: slower than the launches it replaces, DESIGN.md section 7)"""
         _check(lib().ohw_state_set_persistent(self.h, int(on)))
 
     def set_batch_invariant(self, on: bool = True):

@@ -1,5 +1,5 @@
 """Config #5 on one MI355X: large-v3, streaming chunks, beam = 5 (two alternating hipGraph-captured decoder steps), energy VAD
-in front (the reference's RNNoise and Silero models are not available offline; DESIGN.md §9).  A chunk timer of --chunk
+in front (the reference's RNNoise and Silero models are not available offline; DESIGN.md section 2).  A chunk timer of --chunk
 seconds over a synthetic recording; prints the per-chunk latency of StreamingSession.transcribe_job (mel + encoder +
 cross-K/V + beam search of --tokens forced steps, detokenise) and the real-time factor of the stream.
 
