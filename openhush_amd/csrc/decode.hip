@@ -1254,16 +1254,38 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_topk_kernel(SamplerParams p
   st.suppress_eot = 0;
   const int per = (p.n_vocab + BEAM_SPLIT - 1) / BEAM_SPLIT;
   const int lo = part * per, V = lo + per < p.n_vocab ? lo + per : p.n_vocab;
+  // two batches of 13 loads per thread, all of a batch in flight before the first is used (the sampler's pattern): unconditional
+  // loads (clamped address, masked below), the bias behind ONE test of its pointer per batch.  Where the kernel's 47 us go
+  // (builds that return early, rocprofv3): 13 us up to the block sums, 29 us in the 6 + 6 selection rounds of the slice that
+  // holds the timestamps (a 26-value scan and a shuffle tree per round), 5 us publish + merge.
   float v[BEAM_PER_THREAD];
   float lmax = -INFINITY;
+  constexpr int TB = BEAM_PER_THREAD / 2;
 #pragma unroll
-  for (int u = 0; u < BEAM_PER_THREAD; ++u) {
-    const int i = lo + tid + u * BEAM_THREADS;
-    float x = lg[i < V ? i : V - 1];               // unconditional loads (clamped address), masked below
-    if (p.bias) x += p.bias[i < V ? i : V - 1];
-    if (i >= V || !sp_allowed(p, st, i)) x = -INFINITY;
-    v[u] = x;
-    lmax = fmaxf(lmax, x);
+  for (int hb = 0; hb < 2; ++hb) {
+    float vv[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      const int i = lo + tid + (hb * TB + u) * BEAM_THREADS;
+      vv[u] = lg[i < V ? i : V - 1];
+    }
+    if (p.bias) {
+      float bb[TB];
+#pragma unroll
+      for (int u = 0; u < TB; ++u) {
+        const int i = lo + tid + (hb * TB + u) * BEAM_THREADS;
+        bb[u] = p.bias[i < V ? i : V - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < TB; ++u) vv[u] += bb[u];
+    }
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      const int i = lo + tid + (hb * TB + u) * BEAM_THREADS;
+      const float x = (i >= V || !sp_allowed(p, st, i)) ? -INFINITY : vv[u];
+      v[hb * TB + u] = x;
+      lmax = fmaxf(lmax, x);
+    }
   }
   auto block_max = [&](float x) {
     x = wave_max(x);
