@@ -87,6 +87,11 @@ void launch_embed(const void* emb, const float* pos, const int32_t* tok, const i
 // against bank conflicts) and the MFMA B operand is read from there.  Every workgroup redoes the 32-row LN (160 KB of L2 reads) - cheaper
 // than one more dependent launch in a chain of 5 us kernels.
 // ------------------------------------------------------------------------------------------------
+template <typename T, bool SLOTS, bool COH>
+__device__ __forceinline__ void self_attn_row(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc, int n_keys, int b, int m, int h,
+                                              int n_head, int n_ctx, const int32_t* __restrict__ slots, T* __restrict__ out, float* qs, float* ps,
+                                              int lane, unsigned kv_bytes);
+
 constexpr int DG_THREADS = 512;
 constexpr int DG_WAVES = DG_THREADS / 64;
 constexpr int DG_LN_MAXK = 1280;  // fused LayerNorm: 16 threads per row, 20 float4 each
@@ -515,15 +520,29 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
     if (p.bias) v += p.bias[n];
     if constexpr (EPI == DEPI_QKV) {
       const int d = p.d_model;
+      const T v16 = (T)v;
       if (n < d) {
-        ((T*)p.out)[(int64_t)m * d + n] = (T)v;
+        if (p.attn_ticket) {      // the fused self-attention reads it in this launch: written through (sc1)
+          __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7ffffffe, 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v16), ro, (int)(((int64_t)m * d + n) * 2), 0, 16);
+        } else {
+          ((T*)p.out)[(int64_t)m * d + n] = v16;
+        }
       } else {
         const int b = m / p.n_new, i = m % p.n_new;
         const int pos = p.n_past[b] + i;
         const int nn = n < 2 * d ? n - d : n - 2 * d;
         const int h = nn >> 6, dh = nn & 63;
         T* cache = (T*)(n < 2 * d ? p.k_cache : p.v_cache);
-        if (pos < p.n_ctx) cache[((((int64_t)b * p.n_head + h) * p.n_ctx + pos) << 6) + dh] = (T)v;
+        if (pos < p.n_ctx) {
+          const int64_t at = ((((int64_t)b * p.n_head + h) * p.n_ctx + pos) << 6) + dh;
+          if (p.attn_ticket) {
+            __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cache, 0, (unsigned)p.kv_bytes, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v16), rc, (int)(at * 2), 0, 16);
+          } else {
+            cache[at] = v16;
+          }
+        }
       }
     } else if constexpr (EPI == DEPI_BIAS_T) {
       ((T*)p.out)[(int64_t)m * p.ld_out + n] = (T)v;
@@ -533,6 +552,36 @@ __global__ __launch_bounds__(DG_THREADS, 2) void dec_gemm_kernel(DecGemmParams p
       ((float*)p.out)[(int64_t)m * p.ld_out + n] = resid_old[t] + v;
     } else if constexpr (EPI == DEPI_LOGITS) {
       if (m % p.n_new == p.n_new - 1) ((float*)p.out)[(int64_t)(m / p.n_new) * p.ld_out + n] = v;
+    }
+  }
+  if constexpr (EPI == DEPI_QKV && (NT == 1 || NT == 2 || NT == 4)) {
+    if (p.attn_ticket) {
+      // Single-token steps of at most 16 rows: the masked self-attention of a head runs HERE, in the workgroup that publishes the
+      // last of the head's q / k / v columns (12 / NT workgroups per head) - one launch less per layer (an option, OFF: measured
+      // 1.6 us per layer slower than the boundary it removes, engine.hip).  Hand-off form as in the split-K path above: the columns were stored
+      // write-through (sc1), every wave drains its stores, one agent-scope add per workgroup; the last adder reads q and the
+      // cache with sc1 loads (self_attn_row<COH>): same arithmetic, same order, same bits as self_attn_kernel.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                  // the partial tiles are consumed: their LDS serves from here on
+      volatile unsigned* s_attn_ticket = (volatile unsigned*)((float*)part + DG_WAVES * 128);   // (no static LDS: the LN image already takes the CU's 160 KB)
+      const int sec_tiles = p.d_model / 16;
+      const int head = ((nt0 % sec_tiles) * 16) >> 6;
+      if (tid == 0) *s_attn_ticket = __hip_atomic_fetch_add(p.attn_ticket + head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (*s_attn_ticket != 3u * (4 / NT) - 1u) return;
+      if (tid == 0) __hip_atomic_store(p.attn_ticket + head, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+      float* qs = (float*)part + wave * 128;          // 512 B of LDS per wave
+      float* ps = qs + 64;
+      for (int m = wave; m < p.M; m += DG_WAVES) {
+        int n_keys = p.n_past[m] + 1;
+        if (n_keys > p.n_ctx) n_keys = p.n_ctx;
+        if (p.attn_slots)
+          self_attn_row<T, true, true>((const T*)p.out, (const T*)p.k_cache, (const T*)p.v_cache, n_keys, m, m, head, p.n_head, p.n_ctx,
+                                       p.attn_slots + (int64_t)m * p.n_ctx, (T*)p.attn_out, qs, ps, lane, (unsigned)p.kv_bytes);
+        else
+          self_attn_row<T, false, true>((const T*)p.out, (const T*)p.k_cache, (const T*)p.v_cache, n_keys, m, m, head, p.n_head, p.n_ctx,
+                                        nullptr, (T*)p.attn_out, qs, ps, lane, (unsigned)p.kv_bytes);
+      }
     }
   }
   TRACE(16 + EPI * 2 + (LN ? 1 : 0), 3);
@@ -618,33 +667,33 @@ void launch_dec_gemm(const DecGemmParams& p, int epilogue, hipStream_t s) {
   HIP_CHECK(hipGetLastError());
 }
 
-// ------------------------------------------------------------------------------------------------
-// masked self-attention over the KV cache: one wave per (row m, head)
-// ------------------------------------------------------------------------------------------------
-template <typename T, bool SLOTS>
-__global__ __launch_bounds__(64) void self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
-                                                       const int32_t* __restrict__ n_past, T* __restrict__ out, int n_new,
-                                                       int n_head, int n_ctx, const int32_t* __restrict__ kv_slot) {
-  // One wave per (row, head).  Keys are processed in chunks of 64: lane j owns key (chunk*64 + j) for the
-  // score, lane = dh for P.V.  Every global load of a chunk (the lane's K row: 8 x 16 B, and the chunk's V
-  // column slice: 64 x 2 B) is requested before anything waits: one memory round trip per chunk.
-  // SLOTS (beam search): kv_slot [rows][n_ctx] - the cache row that holds position j of this row's sequence: beams that
-  // continue another beam share its past through this table instead of copying K/V.  A separate instantiation: the
-  // per-key lookups cost the greedy path 2 us per launch (5.9 -> 8.0 us) when they were a run-time branch.
-  __shared__ float qs[64];
-  __shared__ float ps[64];
-  const int lane = threadIdx.x;
-  const int h = blockIdx.x, m = blockIdx.y;
-  const int b = m / n_new, i = m % n_new;
+// One wave, one (row, head).  Keys are processed in chunks of 64: lane j owns key (chunk*64 + j) for the
+// score, lane = dh for P.V.  Every global load of a chunk (the lane's K row: 8 x 16 B, and the chunk's V
+// column slice: 64 x 2 B) is requested before anything waits: one memory round trip per chunk.
+// SLOTS (beam search): kv_slot [rows][n_ctx] - the cache row that holds position j of this row's sequence: beams that
+// continue another beam share its past through this table instead of copying K/V.  A separate instantiation: the
+// per-key lookups cost the greedy path 2 us per launch (5.9 -> 8.0 us) when they were a run-time branch.
+// COH: q and the cache rows may have been written by OTHER workgroups of the same launch (the fused form inside the QKV
+// launch): every load of them is a write-through-coherent one (buffer loads with sc1); arithmetic and order are the same, so
+// the two forms give the same bits.
+template <typename T, bool SLOTS, bool COH>
+__device__ __forceinline__ void self_attn_row(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc, int n_keys, int b, int m, int h,
+                                              int n_head, int n_ctx, const int32_t* __restrict__ slots, T* __restrict__ out, float* qs, float* ps,
+                                              int lane, unsigned kv_bytes) {
   const int d = n_head * 64;
-  TRACE(2, 0);
-  int n_keys = n_past[b] + i + 1;
-  if (n_keys > n_ctx) n_keys = n_ctx;
   const int64_t row_stride = (int64_t)n_head * n_ctx << 6;
   const T* kb = kc + ((int64_t)h * n_ctx << 6);
   const T* vb = vc + ((int64_t)h * n_ctx << 6);
-  const int32_t* slots = SLOTS ? kv_slot + (int64_t)b * n_ctx : nullptr;
-  qs[lane] = (float)q[(int64_t)m * d + h * 64 + lane] * 0.125f;
+  __amdgpu_buffer_rsrc_t rq, rk, rv;
+  if constexpr (COH) {
+    rq = __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, 0x7ffffffe, 0x00020000);
+    rk = __builtin_amdgcn_make_buffer_rsrc((void*)kc, 0, kv_bytes, 0x00020000);
+    rv = __builtin_amdgcn_make_buffer_rsrc((void*)vc, 0, kv_bytes, 0x00020000);
+    const unsigned short qr = __builtin_amdgcn_raw_buffer_load_b16(rq, (int)(((int64_t)m * d + h * 64 + lane) * 2), 0, 16);
+    qs[lane] = (float)__builtin_bit_cast(T, qr) * 0.125f;
+  } else {
+    qs[lane] = (float)q[(int64_t)m * d + h * 64 + lane] * 0.125f;
+  }
   float m_run = -INFINITY, l_run = 0.f, o = 0.f;
   for (int c0 = 0; c0 < n_keys; c0 += 64) {
     const int nk = n_keys - c0 < 64 ? n_keys - c0 : 64;
@@ -654,17 +703,29 @@ __global__ __launch_bounds__(64) void self_attn_kernel(const T* __restrict__ q, 
     // against 2.9 without the table, profiles/r03_streaming_beam5_graphs_on_kernel_stats.csv)
     const int sk = SLOTS ? slots[jk] : b;
     vec8_t<T> kr[8];
-    const vec8_t<T>* kp = (const vec8_t<T>*)(kb + sk * row_stride + ((int64_t)jk << 6));
+    if constexpr (COH) {
+      const int kof = (int)((((int64_t)h * n_ctx << 6) + sk * row_stride + ((int64_t)jk << 6)) * 2);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) kr[c] = kp[c];
+      for (int c = 0; c < 8; ++c) kr[c] = __builtin_bit_cast(vec8_t<T>, __builtin_amdgcn_raw_buffer_load_b128(rk, kof + c * 16, 0, 16));
+    } else {
+      const vec8_t<T>* kp = (const vec8_t<T>*)(kb + sk * row_stride + ((int64_t)jk << 6));
+#pragma unroll
+      for (int c = 0; c < 8; ++c) kr[c] = kp[c];
+    }
     T vr[64];
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
       const int jj = j < nk ? c0 + j : c0;
       const int sv = SLOTS ? __builtin_amdgcn_readlane(sk, j < nk ? j : 0) : b;
-      vr[j] = vb[sv * row_stride + ((int64_t)jj << 6) + lane];
+      if constexpr (COH) {
+        const unsigned short vraw = __builtin_amdgcn_raw_buffer_load_b16(rv, (int)((((int64_t)h * n_ctx << 6) + sv * row_stride + ((int64_t)jj << 6) + lane) * 2), 0, 16);
+        vr[j] = __builtin_bit_cast(T, vraw);
+      } else {
+        vr[j] = vb[sv * row_stride + ((int64_t)jj << 6) + lane];
+      }
     }
-    __syncthreads();   // qs (first chunk) / ps of the previous chunk consumed
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // qs (first chunk) / ps of the previous chunk consumed (one wave: program order)
+    __builtin_amdgcn_wave_barrier();
     float sc = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c)
@@ -674,16 +735,37 @@ __global__ __launch_bounds__(64) void self_attn_kernel(const T* __restrict__ q, 
     const float m_new = fmaxf(m_run, wave_max(sc));
     const float alpha = __expf(m_run - m_new);
     const float pe = lane < nk ? __expf(sc - m_new) : 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     ps[lane] = pe;
     l_run = l_run * alpha + wave_sum(pe);
     m_run = m_new;
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < 64; ++j) acc += ps[j] * (float)vr[j];   // masked keys carry p = 0
     o = o * alpha + acc;
   }
   out[act_tiled_offset(m, h * 64 + lane, d)] = (T)(o / l_run);
+}
+
+// ------------------------------------------------------------------------------------------------
+// masked self-attention over the KV cache: one wave per (row m, head)
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool SLOTS>
+__global__ __launch_bounds__(64) void self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
+                                                       const int32_t* __restrict__ n_past, T* __restrict__ out, int n_new,
+                                                       int n_head, int n_ctx, const int32_t* __restrict__ kv_slot) {
+  __shared__ float qs[64];
+  __shared__ float ps[64];
+  const int lane = threadIdx.x;
+  const int h = blockIdx.x, m = blockIdx.y;
+  const int b = m / n_new, i = m % n_new;
+  TRACE(2, 0);
+  int n_keys = n_past[b] + i + 1;
+  if (n_keys > n_ctx) n_keys = n_ctx;
+  self_attn_row<T, SLOTS, false>(q, kc, vc, n_keys, b, m, h, n_head, n_ctx, SLOTS ? kv_slot + (int64_t)b * n_ctx : nullptr, out, qs, ps, lane, 0u);
   TRACE(2, 3);
 }
 template <typename T>

@@ -135,6 +135,8 @@ struct ohw_state {
   DevBuf ps_layers, ps_gran, ps_words;
   PersistParams ps_layout{};         // region offsets of the arena
   bool persist = false;              // OHW_DEC_PERSIST / ohw_state_set_persistent (off: measured slower than the launches)
+  bool fuse_attn = false;            // OHW_DEC_FUSE_ATTN=1: small single-token steps run their self-attention inside the QKV launch (measured slower: off)
+  DevBuf attn_ticket;                // u32 [n_text_head], zero between launches
   int persist_launches = 0;
   int n_cu = 0;
   int step_captures = 0;
@@ -235,6 +237,8 @@ void state_alloc(ohw_state* st) {
   // other lanes to leave the library
   st->graph_max_batch = env_int("OHW_GRAPH_MAX_BATCH", 32, 1, 1 << 20);
   st->persist = env_int("OHW_DEC_PERSIST", 0, 0, 1) != 0;
+  st->fuse_attn = env_int("OHW_DEC_FUSE_ATTN", 0, 0, 1) != 0;
+  st->attn_ticket.alloc((size_t)hp.n_text_head * 4, true);
   (void)hipDeviceGetAttribute(&st->n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
   st->postnorm = env_int("OHW_DEC_POSTNORM", 0, 0, 1) != 0 && dec_ksplit_long() == 1 && dec_ksplit_short() == 1 && dt % 32 == 0;
   st->dx16.alloc(m_tiles * dt * 2, true);
@@ -441,6 +445,11 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
     ProfScope ps(st, cls, 2.0 * (double)N * K);
     launch_dec_gemm<T>(p, epi, s);
   };
+  // OHW_DEC_FUSE_ATTN=1: single-token steps of at most 16 rows run their self-attention inside the QKV launch (decode.hip,
+  // self_attn_row<COH>): one launch less per layer, the same bits - and 1.6 us per layer SLOWER (large-v3, one row: 77.3 against
+  // 74.9 ms per 48-step chunk): the drain of the write-through stores, the ticket and the loads from beyond L2 are three dependent
+  // round trips, a kernel boundary plus the separate launch's first bytes two.  Off.
+  const bool fuse_attn = st->fuse_attn && n_new == 1 && M <= 16 && !pn && d % 64 == 0 && kv_layer * 2 < ((int64_t)1 << 31) && st->attn_ticket.p;
   for (int l = 0; l < L; ++l) {
     const DecLayerW& w = c->dec[l];
     T* kc = (T*)st->self_kv.p + (int64_t)(2 * l) * kv_layer;
@@ -452,10 +461,11 @@ void run_decoder_step(ohw_state* st, int B, int n_new, const int32_t* tok_src = 
       p.w = w.wqkv.p; p.bias = w.bqkv.as<float>(); p.out = st->dq.p;
       p.M = M; p.N = 3 * d; p.K = d; p.n_new = n_new; p.ld_out = d;
       p.k_cache = kc; p.v_cache = vc; p.n_past = n_past; p.d_model = d; p.n_head = H; p.n_ctx = C;
+      if (fuse_attn) { p.attn_ticket = st->attn_ticket.as<unsigned>(); p.attn_out = st->da.p; p.attn_slots = kv_slot; p.kv_bytes = kv_layer * 2; }
       ProfScope ps(st, OHW_PROF_DEC_GEMM_QKV, 2.0 * (3.0 * d * d));
       launch_dec_gemm<T>(p, DEPI_QKV, s);
     }
-    launch_self_attn<T>(st->dq.p, kc, vc, n_past, st->da.p, M, n_new, H, C, s, kv_slot);
+    if (!fuse_attn) launch_self_attn<T>(st->dq.p, kc, vc, n_past, st->da.p, M, n_new, H, C, s, kv_slot);
     gemm(st->da.p, nullptr, w.wo, w.bo, st->dx.p, d, d, DEPI_BIAS_RESID, d);
     gemm(st->dx.p, &w.lnx, w.wxq, w.bxq, st->dq.p, d, d, DEPI_BIAS_T, d, &w.sxq);
     {

@@ -84,6 +84,12 @@ struct DecGemmParams {
   // DEPI_BIAS_RESID producers: besides x (f32) also its 16-bit tiled copy and this tile's statistics (all null: off)
   void* x16_out;                    // T tiles [ceil(M/16)][N/32][64][8]
   float* stat_out;                  // f32 [M][N/16][2]
+  // DEPI_QKV, single-token steps of at most 16 rows (attn_ticket != null): the masked self-attention of a head runs INSIDE this
+  // launch, in the workgroup that publishes the last of the head's q / k / v columns (decode.hip) - no self-attention launch
+  unsigned* attn_ticket;            // [n_head], zero between launches (the kernel re-arms it)
+  void* attn_out;                   // T activation tiles [1][d_model/32][64][8]: what launch_self_attn would have written
+  const int32_t* attn_slots;        // beam search: i32 [rows][n_ctx] (launch_self_attn's kv_slot), else null
+  int64_t kv_bytes;                 // bytes of one layer's K (or V) cache: bound of the kernel's buffer descriptors
 };
 template <typename T> void launch_dec_gemm(const DecGemmParams& p, int epilogue, hipStream_t s);
 
