@@ -1337,9 +1337,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_topk_kernel(SamplerParams p
   const int per = (p.n_vocab + BEAM_SPLIT - 1) / BEAM_SPLIT;
   const int lo = part * per, V = lo + per < p.n_vocab ? lo + per : p.n_vocab;
   // two batches of 13 loads per thread, all of a batch in flight before the first is used (the sampler's pattern): unconditional
-  // loads (clamped address, masked below), the bias behind ONE test of its pointer per batch.  Where the kernel's 47 us go
-  // (builds that return early, rocprofv3): 13 us up to the block sums, 29 us in the 6 + 6 selection rounds of the slice that
-  // holds the timestamps (a 26-value scan and a shuffle tree per round), 5 us publish + merge.
+  // loads (clamped address, masked below), the bias behind ONE test of its pointer per batch.
   float v[BEAM_PER_THREAD];
   float lmax = -INFINITY;
   constexpr int TB = BEAM_PER_THREAD / 2;
@@ -1399,35 +1397,50 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_topk_kernel(SamplerParams p
     }
   }
   const float sum_all = block_sum(s_all), sum_ts = block_sum(s_ts), text_max = block_max(t_max);
-  // The slice's K + 1 best per kind (0: text, 1: timestamps; a slice without timestamps skips theirs): every WAVE first takes the
-  // K + 1 best of its own 64 x 26 values by itself - rounds of arg-max over registers and shuffles, a picked token struck out, no
-  // barrier - then wave 0 takes the K + 1 best of the waves' 4 x (K + 1) (a round with three barriers and a serial scan each took
-  // the kernel to 47 us)
+  // The slice's K + 1 best per kind (0: text, 1: timestamps).  Every LANE first sorts the best six of its own 26 values per kind into
+  // registers (one pass, branch-free insertion; equal values keep the lower index in front); a wave's K + 1 best are then K + 1
+  // rounds over the lanes' list HEADS - a shuffle tree, the winner pops its list - and wave 0 takes the K + 1 best of the waves'
+  // 4 x (K + 1).  (Rounds that re-scanned the 26 values and struck the winner out took 29 of the kernel's 47 us.)
   __shared__ float sh_wv[2][BEAM_THREADS / 64][6];
   __shared__ int sh_wi[2][BEAM_THREADS / 64][6];
   const int wv = tid >> 6, ln = tid & 63;
-  for (int kind = 0; kind < 2; ++kind) {
-    const bool any = kind == 0 ? lo < p.ts_begin : V > p.ts_begin;       // uniform
-    for (int c = 0; c < K1; ++c) {
-      float bv = -INFINITY; int bi = 0x7fffffff;
-      if (any) {
+  float lv[2][6]; int li[2][6];
 #pragma unroll
-        for (int u = 0; u < BEAM_PER_THREAD; ++u) {
-          const int i = lo + tid + u * BEAM_THREADS;
-          const bool mine = kind == 0 ? i < p.ts_begin : i >= p.ts_begin;
-          if (mine && (v[u] > bv || (v[u] == bv && v[u] > -INFINITY && i < bi))) { bv = v[u]; bi = i; }
-        }
+  for (int kind = 0; kind < 2; ++kind)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
-          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        if (bv > -INFINITY) {
+    for (int k = 0; k < 6; ++k) { lv[kind][k] = -INFINITY; li[kind][k] = 0x7fffffff; }
 #pragma unroll
-          for (int u = 0; u < BEAM_PER_THREAD; ++u) if (lo + tid + u * BEAM_THREADS == bi) v[u] = -INFINITY;
-        }
+  for (int u = 0; u < BEAM_PER_THREAD; ++u) {
+    const int i = lo + tid + u * BEAM_THREADS;
+    const bool is_ts = i >= p.ts_begin;
+#pragma unroll
+    for (int kind = 0; kind < 2; ++kind) {
+      float x = (kind == 1) == is_ts ? v[u] : -INFINITY; int xi = i;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {                       // strict >: an equal value with a higher index stays behind
+        const bool up = x > lv[kind][k];
+        const float tv = up ? lv[kind][k] : x; const int ti = up ? li[kind][k] : xi;
+        lv[kind][k] = up ? x : lv[kind][k]; li[kind][k] = up ? xi : li[kind][k];
+        x = tv; xi = ti;
       }
-      if (ln == 0) { sh_wv[kind][wv][c] = bv; sh_wi[kind][wv][c] = bv > -INFINITY ? bi : -1; }
+    }
+  }
+  for (int c = 0; c < K1; ++c) {
+#pragma unroll
+    for (int kind = 0; kind < 2; ++kind) {
+      float bv = lv[kind][0]; int bi = bv > -INFINITY ? li[kind][0] : 0x7fffffff;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      const bool got = bv > -INFINITY;
+      if (got && lv[kind][0] == bv && li[kind][0] == bi) {        // the winner pops its list
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { lv[kind][k] = lv[kind][k + 1]; li[kind][k] = li[kind][k + 1]; }
+        lv[kind][5] = -INFINITY; li[kind][5] = 0x7fffffff;
+      }
+      if (ln == 0) { sh_wv[kind][wv][c] = bv; sh_wi[kind][wv][c] = got ? bi : -1; }
     }
   }
   __syncthreads();
