@@ -327,6 +327,36 @@ def test_long_audio_overlapped_schedules_equal_sequential(E, models, monkeypatch
     e1.close(); e2.close(); e3.close()
 
 
+def test_the_longest_valid_recording_and_the_first_length_beyond_it(E, models):
+    """validate_audio's upper bound (reference src/engine/validation.rs:67-72: more than 7 200 s is "Audio too long"): exactly two
+    hours = 240 windows goes through ohw_engine_transcribe (LANES over 15 batches of 16), every window's tokens equal to the window
+    taken alone; the first length whose f32 duration exceeds 7 200 is refused before any device work."""
+    _, path, _, _ = models
+    n_win = 240
+    base = [synth.synth_audio(200 + w) for w in range(6)]
+    pcm = np.concatenate([base[w % 6] for w in range(n_win)])
+    assert pcm.size == 7200 * 16000
+    eng = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_BF16, 16)
+    eng.set_decode_policy(temperature_inc=0.0)
+    r = eng.transcribe(E.AudioBuffer(pcm, 16000))
+    tr = eng.last_trace()
+    assert len(tr) == n_win and len(r.text) > 0
+    one = E.WhisperEngine.new(path, "auto", False, True, 0, E.OHW_DTYPE_BF16, 1)
+    one.set_decode_policy(temperature_inc=0.0)
+    for w in (0, 1, 5):
+        one.transcribe(E.AudioBuffer(base[w], 16000))
+        alone = one.last_trace()[0]
+        for k in (w, w + 6 * 13, w + 6 * 39):            # the same audio at three places of the recording (three different batches)
+            assert tr[k][1:] == alone[1:], (w, k)          # (window index, temperature, tokens): the window index differs
+    # the bound is tested in f32 like the reference's (`samples.len() as f32 / sample_rate as f32`): 7 200 s + 4 samples still rounds to
+    # 7 200.0 and passes, + 8 samples is the first length that reads 7 200.0005 and is refused before any device work
+    assert E.validate_audio(np.concatenate([pcm, np.zeros(4, np.float32)]), 16000).sample_count == pcm.size + 4
+    with pytest.raises(E.ValidationFailed) as ei:
+        eng.transcribe(E.AudioBuffer(np.concatenate([pcm, np.zeros(8, np.float32)]), 16000))
+    assert "too long" in str(ei.value).lower()
+    eng.close(); one.close()
+
+
 def test_batch_invariant_decode_is_independent_of_the_batch(E, models):
     """ohw_state_set_batch_invariant: the same window alone, in a batch of 3 and (with 30 more) in a batch of 33 rows gives
     bit-identical logits (prompt pass and single-token steps) and the same greedy tokens and log-probabilities; without the

@@ -53,6 +53,19 @@ def test_validate_audio_reference_cases():
     assert ei.value.kind == "TooLong"
 
 
+def test_validate_audio_duration_bound_is_tested_in_f32_like_the_reference():
+    """`samples.len() as f32 / sample_rate as f32 > 7200.0` (src/engine/validation.rs:64-72): two hours + 4 samples still reads
+    7 200.0 and is valid, + 8 samples (7 200.0005) is the first length that is too long"""
+    n = 7200 * 16000
+    z = np.zeros(n + 8, np.float32)
+    z[::16000] = 0.25                                   # not silent: only the duration is under test
+    info = E.validate_audio(z[:n + 4], 16000)
+    assert info.sample_count == n + 4 and info.duration_secs == 7200.0
+    with pytest.raises(E.ValidationFailed) as ei:
+        E.validate_audio(z, 16000)
+    assert ei.value.kind == "TooLong"
+
+
 def test_validate_audio_matches_oracle_statistics():
     from oracle import oracle
     rng = np.random.default_rng(3)
