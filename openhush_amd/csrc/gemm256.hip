@@ -6,17 +6,20 @@
 // Structure (after cdna_hip_programming.md section 5, "Pipelining across barriers" / the 8-phase idea):
 //   * 512 threads = 8 waves (2 along m x 4 along n), each wave a 128x64 output tile = 8x4 MFMA tiles of
 //     16x16x32 (128 accumulator VGPRs); one workgroup per CU.
-//   * LDS: ONE 128-KiB array = 2 stages x (256 x 64 A + 256 x 64 W) x 2 B.  Rows are 128 B = one whole cache line of
-//     the operand: a global_load_lds_dwordx4 wave-instruction brings 8 rows x 128 B (the first version staged k-halves
-//     with 64-byte rows, i.e. every line was fetched in two half-used pieces by two different instructions).  The eight
+//   * LDS: ONE 160-KiB array = 3 stages of the A tile (256 rows x 64 k) + 2 stages of the W tile.  Rows are 128 B = one whole
+//     cache line of the operand: a global_load_lds_dwordx4 wave-instruction brings 8 rows x 128 B (the first version staged
+//     k-halves with 64-byte rows, i.e. every line was fetched in two half-used pieces by two different instructions).  The eight
 //     16-byte chunks of a row are XOR-swizzled with (row >> 1) & 7, which makes every ds_read_b128 fragment read
 //     conflict-free; the LDS destination of the DMA is lane-linear, so the swizzle goes on the per-lane SOURCE
 //     address and on the read.
 //   * a K-tile is consumed in two phases (k 0..31, then k 32..63), 32 MFMAs per wave each.  The two waves of
 //     a SIMD are staggered by one barrier interval: one reads its fragments for the next phase while the
-//     other runs MFMAs on fragments already in registers.  A stage is refilled (8 DMA instructions per wave) in each
-//     wave's first read interval after the barrier that retired the stage's last readers; the data is needed two
-//     phase-times later, behind s_waitcnt vmcnt(0) (nothing younger is in flight at that point) + raw s_barrier.
+//     other runs MFMAs on fragments already in registers.  In K-tile kt's first read interval a wave requests its share of
+//     W(kt + 1) and then of A(kt + 2) (4 DMA instructions each), into the stages K-tile kt - 1 was read from; the wait in front
+//     of K-tile kt + 1 is s_waitcnt vmcnt(4) - everything but that A tile - + raw s_barrier.  The activation panels come from
+//     beyond L2 for the first tile of an XCD that touches them (all of them when N = 1280: five n-tiles per panel), and one
+//     K-tile time (1.5 us) does not cover that latency: the third A stage took 2 - 4.5 % off the N = 1280 launches (round 3,
+//     tools/gemm_probe.py: 515 / 819 / 1505 us at K = 1280 / 2560 / 5120 against 527 / 844 / 1575), 0 - 1.5 % off the others.
 // Roofline: MFMA.
 #include <algorithm>
 #include <cstdlib>
@@ -28,8 +31,10 @@ namespace ohw {
 
 constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
 constexpr int G2_THREADS = 512;
-constexpr int G2_STAGE = 65536;   // bytes per stage: A 256 rows x 128 B | W 256 rows x 128 B
-constexpr int G2_WOFF = 32768;
+constexpr int G2_OPSTAGE = 32768;  // bytes of one operand's K-tile: 256 rows x 128 B
+constexpr int G2_NA = 3;           // A stages at 0, 32 KiB, 64 KiB: the activation panels mostly come from beyond L2 (one use per m-tile and XCD)
+constexpr int G2_WBASE = G2_NA * G2_OPSTAGE;   // 2 W stages behind them (the weight panels stay in the L2s)
+constexpr int G2_LDS = G2_WBASE + 2 * G2_OPSTAGE;   // 160 KiB
 
 __device__ __forceinline__ int g2_key(int row) { return (row >> 1) & 7; }
 
@@ -57,11 +62,6 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   const unsigned n_tiles_n = (unsigned)(p.N / G2_BN);
   const unsigned n_tiles_m = (unsigned)((p.M + G2_BM - 1) / G2_BM);
   const unsigned nwg = n_tiles_n * n_tiles_m;
-  // Tiles per workgroup: ONE (grid = tiles) or - the persistent form, K-tile count even - tiles d, d + G, d + 2G, ... of a grid of G
-  // workgroups, one per CU (G a multiple of 8, so d % 8 - the XCD under round-robin placement - is the same for all of a
-  // workgroup's tiles and the order in which an XCD meets its tiles is the order the dispatcher would have handed them out in).
-  const unsigned G = gridDim.x;
-
   const T* __restrict__ A = (const T*)p.A;
   const T* __restrict__ W = (const T*)p.W;
 
@@ -98,18 +98,28 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   };
   const int KT = (int)(p.K / G2_BK);
 
-  // the 8 DMA instructions of this wave for K-tile kt
-  auto issue_tile = [&](int kt) {
-    const int koff = kt * G2_BK;
-    const int buf = (kt & 1) * G2_STAGE;
+  // the DMA instructions of this wave for K-tile kt: 4 for its share of the A tile, 4 for the W tile
+  auto issue_A = [&](int kt) {
+    const unsigned koff = (unsigned)(kt * G2_BK * 2);
+    const int buf = (kt % G2_NA) * G2_OPSTAGE;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)A + (size_t)(a_off[j] + (unsigned)(koff * 2))),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)A + (size_t)(a_off[j] + koff)),
                                        (__attribute__((address_space(3))) void*)(smem + buf + (wave * 4 + j) * 1024), 16, 0, 0);
+  };
+  auto issue_W = [&](int kt) {
+    const unsigned koff = (unsigned)(kt * G2_BK * 2);
+    const int buf = G2_WBASE + (kt & 1) * G2_OPSTAGE;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W + (size_t)(w_off[j] + (unsigned)(koff * 2))),
-                                       (__attribute__((address_space(3))) void*)(smem + buf + G2_WOFF + (wave * 4 + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W + (size_t)(w_off[j] + koff)),
+                                       (__attribute__((address_space(3))) void*)(smem + buf + (wave * 4 + j) * 1024), 16, 0, 0);
+  };
+  // K-tile kt's read interval: W(kt + 1) first, then A(kt + 2) - the wait in front of K-tile kt + 1 leaves exactly the four
+  // youngest operations (that A tile) in flight
+  auto issue_ahead = [&](int kt) {
+    if (kt + 1 < KT) issue_W(kt + 1);
+    if (kt + 2 < KT) issue_A(kt + 2);
   };
 
   // fragment read offsets inside a stage: row = tile row + (lane & 15), chunk (4h + (lane >> 4)) ^ key(row);
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   const int fr = lane & 15, fq = lane >> 4;
   const int fkey = g2_key(fr);
   const int a_row = (wm * 128 + fr) * 128;
-  const int w_row = G2_WOFF + (wn * 64 + fr) * 128;
+  const int w_row = G2_WBASE + (wn * 64 + fr) * 128;
 
   // A "phase" P = 2*kt + h consumes k-half h of K-tile kt (32 MFMAs per wave) from stage kt & 1.
   //
@@ -134,12 +144,13 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   f32x4 acc[8][4];
   vec8 fw[4], fa[8];
   auto read_frags = [&](int P) {
-    const int cur = ((P >> 1) & 1) * G2_STAGE;
+    const int kt = P >> 1;
+    const int acur = (kt % G2_NA) * G2_OPSTAGE, wcur = (kt & 1) * G2_OPSTAGE;
     const int ch = (((P & 1) * 4 + fq) ^ fkey) << 4;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) fw[ni] = *(const vec8*)(smem + cur + w_row + ch + ni * 2048);
+    for (int ni = 0; ni < 4; ++ni) fw[ni] = *(const vec8*)(smem + wcur + w_row + ch + ni * 2048);
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) fa[mi] = *(const vec8*)(smem + cur + a_row + ch + mi * 2048);
+    for (int mi = 0; mi < 8; ++mi) fa[mi] = *(const vec8*)(smem + acur + a_row + ch + mi * 2048);
   };
   auto compute = [&]() {
     __builtin_amdgcn_s_setprio(1);
@@ -149,9 +160,13 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Ops::mfma16(fw[ni], fa[mi], acc[mi][ni]);
     __builtin_amdgcn_s_setprio(0);
   };
-  // barrier that opens an EVEN interval 2*Pn: when Pn starts a K-tile, every wave's share of that tile must have landed
+  // barrier that opens an EVEN interval 2*Pn: when Pn starts a K-tile k, every wave's share of A(k) and W(k) must have landed; the A tile
+  // for k + 1 (this wave's four youngest operations, if there is one) stays in flight
   auto open_even = [&](int Pn) {
-    if (Pn < NP && (Pn & 1) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (Pn < NP && (Pn & 1) == 0) {
+      if ((Pn >> 1) + 1 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -167,11 +182,14 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  unsigned d = blockIdx.x;
+  // One tile per workgroup.  (Round 3 also built the persistent form - a workgroup per CU walking tiles d, d + G, ... with the next
+  // tile's first K-tile requested inside the epilogue; it took the 1.4 us of first bytes and the 0.9 us of dispatch out of a tile
+  // and gave them back to the imbalance of a static tile assignment: DESIGN.md Appendix A.  Removed with the third A stage.)
+  const unsigned d = blockIdx.x;
   tile_setup(d);
-  issue_tile(0);
-#pragma unroll 1
-  for (;;) {
+  issue_A(0); issue_W(0);
+  if (KT > 1) issue_A(1);
+  {
 #ifdef OHW_TRACE
     unsigned g2_slot = G2_TRACE_CAP;
     if (tid == 0) {
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
         if (P == 0) G2T(3);
 #endif
         read_frags(P);
-        if ((P & 1) == 0 && (P >> 1) + 1 < KT) issue_tile((P >> 1) + 1);   // the other stage: its readers are behind the barrier above
+        if ((P & 1) == 0) issue_ahead(P >> 1);   // into the stages K-tile kt - 1 was read from: their readers are behind the barrier above
         __builtin_amdgcn_sched_barrier(0);
         open_odd();
         compute();
@@ -222,7 +240,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
       for (int P = 0; P < NP; ++P) {
         open_odd();
         read_frags(P);
-        if ((P & 1) == 0 && (P >> 1) + 1 < KT) issue_tile((P >> 1) + 1);   // this wave's share, one interval after the partner group's
+        if ((P & 1) == 0) issue_ahead(P >> 1);   // this wave's share, one interval after the partner group's
         __builtin_amdgcn_sched_barrier(0);
         open_even(P + 1);
         compute();
@@ -231,18 +249,9 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
     }
     G2T(4);
 
-    // Every fragment read of this tile lies behind the barrier both groups passed last (open_even(NP)): both stages are free.  The
-    // next tile's first K-tile is requested INSIDE this tile's epilogue, as soon as the epilogue no longer needs stage 0's 64 KiB -
-    // its 1.4 us of first bytes and the 0.9 us a fresh workgroup takes to arrive (tools/gemm_trace.py) pass under the stores.
-    const unsigned dn = d + G;
-    const bool more = dn < nwg;
-    auto prefetch_next = [&]() {
-      if (more) { tile_setup(dn); issue_tile(0); }
-    };
-
     // ---- epilogue: lane (fq, fr) holds, for each mi, columns n0 + wn*64 + fq_e*16 + [0,16) of row m ----
-    // (its addresses are built on an opaque copy of the lane id: what is invariant across the tiles of a workgroup would
-    // otherwise be hoisted out of the tile loop and parked in registers through every main loop - the kernel spilled)
+    // (its addresses are built on an opaque copy of the lane id: they are not to be computed ahead of the main loop and parked in
+    // registers through it)
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int fr_e = lane_e & 15, fq_e = lane_e >> 4;
@@ -308,16 +317,12 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
       to_lds(1);
       raw_barrier();
       G2T(9);
-      // round 1: LDS -> registers (the accumulator's are all free now), then the LDS belongs to the next tile
+      // round 1: LDS -> registers (the accumulator's are all free now)
       f32x4 v1[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int lr = wave * 16 + i;
         v1[i] = *(const f32x4*)(smem + lr * 1024 + ((lane_e ^ (lr & 15)) << 4));
-      }
-      if (more) {
-        raw_barrier();
-        prefetch_next();
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -359,7 +364,6 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
         raw_barrier();
         G2T(8);
         T* outp = (T*)p.out;
-        // rows 0 .. 127 (stage 0's 64 KiB) first; then that half of the LDS takes the next tile's first K-tile while rows 128 .. 255 leave
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -372,16 +376,11 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
             const u32x4 d4 = *(const u32x4*)(smem + r * 512 + (((lane_e & 31) ^ (r & 15)) << 4));
             *(u32x4*)(outp + bb * p.c_batch_stride + rr * p.ldc + n0c + (lane_e & 31) * 8) = d4;
           }
-          if (half == 0 && more) {
-            raw_barrier();
-            prefetch_next();
-          }
         }
         stored = true;
       }
     }
     if (!stored) {
-      prefetch_next();                       // no LDS in this epilogue: the whole of it covers the next tile's first bytes
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) {
         const int64_t m = m0c + wm * 128 + mi * 16 + fr_e;
@@ -396,32 +395,20 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
     }
 #ifdef OHW_TRACE
     G2T(6 + (EPI == EPI_BIAS_RESID_F32 ? 5 : 0));
-    if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G2T(5);
 #endif
-    if (!more) break;
-    d = dn;
   }
 }
 
 template <typename T, int EPI>
 static void launch256_one(const GemmParams& p, hipStream_t stream) {
   const unsigned nwg = (unsigned)((p.N / G2_BN) * ((p.M + G2_BM - 1) / G2_BM));
-  ensure_dynamic_lds((const void*)gemm256_kernel<T, EPI>, 2 * G2_STAGE);
+  ensure_dynamic_lds((const void*)gemm256_kernel<T, EPI>, G2_LDS);
   GemmParams q = p;
   static const int gm_env = [] { const char* e = getenv("OHW_GEMM_GM"); return e ? atoi(e) : 0; }();
   q.group_m = gm_env > 0 ? gm_env : 6;   // 6: 1 % faster than 8 at 32 and at 96 windows per pass (round 2 sweep: 4, 6, 8, 16)
-  // OHW_GEMM_PERSIST=1: the persistent form (a workgroup per CU walks tiles d, d + G, ...; K-tile count even: a tile's first K-tile
-  // then always lands in stage 0, the stage its predecessor's epilogue frees first).  Measured, round 3 (tools/gemm_trace.py,
-  // tools/gemm_probe.py, interleaved runs, 96 windows): the first bytes arrive 0.24 instead of 1.4 us after a tile begins and the
-  // 0.9 us of dispatch are gone, but the launch is no faster at K = 1280 (1 215 against 1 217 - 1 228 us for N = 3840) and 6 %
-  // SLOWER at K = 5120: tile times differ by +- 4 % between CUs, the dispatcher gives the faster CUs more tiles and a static
-  // stride cannot; the epilogue grows by the next tile's address arithmetic and one barrier.  Off.
-  static const int persist_env = [] { const char* e = getenv("OHW_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
-  static const int n_cu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-  unsigned grid = nwg;
-  if (persist_env && ((p.K / G2_BK) & 1) == 0) grid = std::min(nwg, (unsigned)std::max(8, n_cu / 8 * 8));
-  hipLaunchKernelGGL((gemm256_kernel<T, EPI>), dim3(grid), dim3(G2_THREADS), 2 * G2_STAGE, stream, q);
+  hipLaunchKernelGGL((gemm256_kernel<T, EPI>), dim3(nwg), dim3(G2_THREADS), G2_LDS, stream, q);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -98,25 +98,6 @@ def test_gemm256_epilogues_and_ragged_last_tile(E, dt, M, N, K):
     _check_gemm_all_epilogues(E, dt, M, N, K)
 
 
-def test_gemm256_persistent_tile_loop_in_a_child_process():
-    """OHW_GEMM_PERSIST=1 (read once per process): a workgroup per CU walks its tiles and requests the next tile's first K-tile inside
-    the epilogue; same checks, one child process"""
-    import os
-    import subprocess
-    import sys
-    code = ("import torch, sys; sys.path.insert(0, %r)\n"
-            "from openhush_amd import engine as E\n"
-            "import tests.test_gpu_kernels as t\n"
-            "for dt in (0, 1):\n"
-            "    for (M, N, K) in t.GEMM256_SHAPES + [(70000, 1280, 128)]:\n"
-            "        t._check_gemm_all_epilogues(E, dt, M, N, K)\n"
-            "print('persistent ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, OHW_GEMM_PERSIST="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and "persistent ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
-
-
 def test_gemm_rejects_bad_shapes(E):
     a = torch.zeros(16, 64, device="cuda", dtype=torch.bfloat16)
     assert E.lib().ohw_dbg_gemm(0, a.data_ptr(), a.data_ptr(), None, a.data_ptr(), 16, 100, 64, E.EPI_BIAS_T, None) == E.OHW_E_INVALID_ARG
