@@ -58,6 +58,20 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+#ifdef OHW_TRACE
+  unsigned g2_slot = G2_TRACE_CAP;
+  if (tid == 0) {
+    g2_slot = atomicAdd(&g2_trace_n, 1u);
+    if (g2_slot < G2_TRACE_CAP) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g2_trace_buf[g2_slot * 12 + 0] = blockIdx.x;
+      g2_trace_buf[g2_slot * 12 + 1] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+    }
+  }
+  G2T(2);
+#endif
 
   const unsigned n_tiles_n = (unsigned)(p.N / G2_BN);
   const unsigned n_tiles_m = (unsigned)((p.M + G2_BM - 1) / G2_BM);
@@ -190,20 +204,6 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmParams p) {
   issue_A(0); issue_W(0);
   if (KT > 1) issue_A(1);
   {
-#ifdef OHW_TRACE
-    unsigned g2_slot = G2_TRACE_CAP;
-    if (tid == 0) {
-      g2_slot = atomicAdd(&g2_trace_n, 1u);
-      if (g2_slot < G2_TRACE_CAP) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g2_trace_buf[g2_slot * 12 + 0] = d;
-        g2_trace_buf[g2_slot * 12 + 1] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
-      }
-    }
-    G2T(2);
-#endif
     // this tile's place (tile_setup's m0 / n0 move on to the NEXT tile inside the epilogue)
     const int64_t m0c = m0, n0c = n0;
     // the lane's 16 bias values, requested before the main loop (four 16-byte loads): at the head of the epilogue they were 16 branchy
